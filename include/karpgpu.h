@@ -1,0 +1,410 @@
+/*
+ * karpgpu.h -- C ABI of libkarpgpu, the MI355X (gfx950) implementation of Karpenter's
+ * provisioning / consolidation bin-packing hot path.
+ *
+ * This is the drop-in boundary: a Go controller keeps its API surface and calls these entry
+ * points through cgo (binding sketch in INTEGRATION.md).  Every entry point is `extern "C"`,
+ * takes plain pointers and sizes, returns an int32 status (0 = KG_OK) and keeps NO caller
+ * pointer after it returns (cgo rule).  Outputs go into caller-allocated buffers with explicit
+ * capacities; a `needed_*` field reports the size that would have been required.
+ *
+ * Reference interfaces replaced (paths relative to the reference checkout):
+ *   cloudprovider.GetInstanceTypes            pkg/cloudprovider/cloudprovider.go:172
+ *   instancetype.DefaultProvider.List         pkg/providers/instancetype/instancetype.go:100-175
+ *   instancetype.NewInstanceType              pkg/providers/instancetype/types.go:51-71
+ *   resolveInstanceTypes (launch filter)      pkg/cloudprovider/cloudprovider.go:267-282
+ *   InstanceTypes.Truncate call site          pkg/providers/instance/instance.go:101 (max 60, :54)
+ *   filterExoticInstanceTypes/filterUnwantedSpot  pkg/providers/instance/instance.go:429-477
+ *   Scheduler.Solve / NodeClaim.Add / ExistingNode.Add / Topology / Preferences / Queue and the
+ *   disruption simulation live in sigs.k8s.io/karpenter v0.37.1-0.20240715214311-a122e25df3de
+ *   (go.mod:34; source absent from the reference checkout -- SURVEY.md Appendix A is the spec).
+ *
+ * Conventions
+ *   - strings: every name (label key/value, resource, instance type, zone ...) is a uint32 index
+ *     into the descriptor's own string table (kg_strtab).  KG_NONE = "no string".
+ *   - quantities: int64 milli-units (cpu "940m" = 940, memory "1Mi" = 1048576000).  Finer than
+ *     milli is not representable -> KG_EUNSUPPORTED, caller uses its CPU path.
+ *   - ranges: {begin,count} into the flat pool of the same descriptor.
+ */
+#ifndef KARPGPU_H
+#define KARPGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KG_NONE 0xFFFFFFFFu
+
+/* status codes */
+enum {
+  KG_OK = 0,
+  KG_EINVAL = 1,       /* malformed descriptor */
+  KG_ENOMEM = 2,       /* host or device allocation failed, or an output buffer is too small */
+  KG_EDEVICE = 3,      /* HIP error; kg_last_error has the text */
+  KG_EUNSUPPORTED = 4, /* input not representable on the device path (caller falls back to CPU) */
+  KG_ESTALE = 5        /* catalog/cluster generation mismatch */
+};
+
+/* requirement operators (corev1.NodeSelectorOperator) */
+enum { KG_OP_IN = 0, KG_OP_NOT_IN = 1, KG_OP_EXISTS = 2, KG_OP_DOES_NOT_EXIST = 3, KG_OP_GT = 4, KG_OP_LT = 5 };
+/* taint effects */
+enum { KG_EFFECT_NONE = 0, KG_EFFECT_NO_SCHEDULE = 1, KG_EFFECT_PREFER_NO_SCHEDULE = 2, KG_EFFECT_NO_EXECUTE = 3 };
+/* toleration operators */
+enum { KG_TOL_EQUAL = 0, KG_TOL_EXISTS = 1 };
+/* topology spread whenUnsatisfiable */
+enum { KG_DO_NOT_SCHEDULE = 0, KG_SCHEDULE_ANYWAY = 1 };
+/* per-pod result kinds */
+enum { KG_POD_UNSCHEDULABLE = 0, KG_POD_EXISTING_NODE = 1, KG_POD_NEW_CLAIM = 2 };
+/* consolidation decisions (disruption Command.Decision()) */
+enum { KG_DECISION_NOOP = 0, KG_DECISION_DELETE = 1, KG_DECISION_REPLACE = 2 };
+
+typedef struct { uint32_t begin, count; } kg_range;
+
+typedef struct {
+  const char* data;        /* concatenated bytes, no terminators needed */
+  const uint32_t* offsets; /* count+1 entries; string i = data[offsets[i] .. offsets[i+1]) */
+  uint32_t count;
+} kg_strtab;
+
+typedef struct {
+  uint32_t key;
+  uint8_t op;         /* KG_OP_* */
+  int32_t min_values; /* -1 = unset (NodeSelectorRequirementWithMinValues) */
+  kg_range values;    /* into pools.req_values (string ids) */
+} kg_requirement;
+
+typedef struct { uint32_t name; int64_t milli; } kg_quantity;
+typedef struct { uint32_t key, value; } kg_label;
+typedef struct { uint32_t key, value; uint8_t effect; } kg_taint;
+typedef struct { uint32_t key /* KG_NONE = empty */; uint32_t value; uint8_t op; uint8_t effect /* KG_EFFECT_NONE = any */; } kg_toleration;
+
+/* metav1.LabelSelector.  is_nil != 0 selects nothing; an empty non-nil selector selects all. */
+typedef struct {
+  uint8_t is_nil;
+  kg_range match_labels; /* into pools.labels */
+  kg_range match_exprs;  /* into pools.reqs, operators In/NotIn/Exists/DoesNotExist */
+} kg_selector;
+
+/* shared flat pools: every descriptor carries one */
+typedef struct {
+  kg_strtab strings;
+  const kg_requirement* reqs;        uint32_t n_reqs;
+  const uint32_t* req_values;        uint32_t n_req_values;
+  const kg_quantity* quantities;     uint32_t n_quantities;
+  const kg_label* labels;            uint32_t n_labels;
+  const kg_taint* taints;            uint32_t n_taints;
+  const kg_toleration* tolerations;  uint32_t n_tolerations;
+  const kg_range* ranges;            uint32_t n_ranges; /* second-level ranges (lists of lists) */
+} kg_pools;
+
+/* ---------------------------------------------------------------- catalog */
+/* cloudprovider.Offering as built at instancetype.go:290-300 */
+typedef struct {
+  uint32_t zone, capacity_type, zone_id /* KG_NONE when the subnet has no zone id */;
+  double price;
+  uint8_t available;
+} kg_offering;
+
+/* cloudprovider.InstanceType as built at types.go:56-66 */
+typedef struct {
+  uint32_t name;
+  kg_range requirements; /* pools.reqs: 26-27 keys, DoesNotExist entries included */
+  kg_range capacity;     /* pools.quantities */
+  kg_range overhead;     /* pools.quantities: KubeReserved+SystemReserved+EvictionThreshold summed */
+  kg_range offerings;    /* into offerings[] */
+} kg_instance_type;
+
+typedef struct {
+  kg_pools pools;
+  const kg_instance_type* types; uint32_t n_types;
+  const kg_offering* offerings;  uint32_t n_offerings;
+} kg_catalog_desc;
+
+/* Raw EC2 facts for one type: the inputs of NewInstanceType (types.go:51).  Lets the library do
+ * the whole List() miss path (instancetype.go:155-172) natively: offerings + requirements +
+ * capacity + overhead. */
+typedef struct {
+  uint32_t name;
+  uint32_t arch;          /* already mapped through AWSToKubeArchitectures (amd64/arm64) */
+  uint8_t first_arch_is_arm64; /* SupportedArchitectures[0]=="arm64" (types.go:219) */
+  uint32_t hypervisor;    /* KG_NONE -> "" */
+  uint32_t cpu_manufacturer; /* raw ProcessorInfo.Manufacturer or KG_NONE */
+  int64_t vcpus, memory_mib;
+  uint8_t encryption_in_transit;
+  int64_t ebs_max_bandwidth_mbps; /* -1 unless EbsOptimizedSupport==default */
+  int64_t network_bandwidth_mbps; /* -1 when not in the bandwidth table */
+  int64_t local_nvme_gb;     /* -1 when no NVMe instance storage (types.go:129) */
+  int64_t instance_storage_total_gb; /* -1 when InstanceStorageInfo or TotalSizeInGB nil (types.go:232) */
+  /* GpuInfo.Gpus, InferenceAcceleratorInfo.Accelerators */
+  kg_range gpus;          /* into devices[] */
+  kg_range accelerators;  /* into devices[] */
+  int64_t efa_max_interfaces; /* 0 when none */
+  /* NetworkInfo */
+  int64_t default_card_max_interfaces; /* NetworkCards[DefaultNetworkCardIndex].MaximumNetworkInterfaces */
+  int64_t ipv4_per_interface;
+  /* VPC limits table (zz_generated.vpclimits.go) */
+  uint8_t has_limits, trunking_compatible;
+  int64_t branch_interfaces, limits_ipv4_per_interface;
+  kg_range usage_classes; /* pools.req_values: "on-demand","spot","capacity-block" */
+  kg_range zones_offered; /* pools.req_values: zones from DescribeInstanceTypeOfferings */
+} kg_ec2_type;
+typedef struct { uint32_t name, manufacturer; int64_t count, memory_mib; } kg_ec2_device;
+
+typedef struct { uint32_t zone, zone_id /* KG_NONE */; } kg_subnet;
+typedef struct { uint32_t instance_type, zone; double price; } kg_spot_price;
+typedef struct { uint32_t instance_type; double price; } kg_od_price;
+typedef struct { uint32_t capacity_type, instance_type, zone; } kg_unavailable; /* ICE cache key ct:it:zone */
+
+enum { KG_AMI_AL2 = 0, KG_AMI_AL2023 = 1, KG_AMI_BOTTLEROCKET = 2, KG_AMI_UBUNTU = 3,
+       KG_AMI_WINDOWS2019 = 4, KG_AMI_WINDOWS2022 = 5, KG_AMI_CUSTOM = 6 };
+
+typedef struct {
+  kg_pools pools;
+  const kg_ec2_type* types;      uint32_t n_types;
+  const kg_ec2_device* devices;  uint32_t n_devices;
+  const kg_subnet* subnets;      uint32_t n_subnets;
+  const kg_od_price* od_prices;  uint32_t n_od_prices;
+  const kg_spot_price* spot_prices; uint32_t n_spot_prices;
+  const kg_unavailable* unavailable; uint32_t n_unavailable;
+  uint32_t region;
+  uint8_t ami_family;                 /* KG_AMI_* */
+  /* options.Options (pkg/operator/options/options.go:44,46) */
+  double vm_memory_overhead_percent;  /* 0.075 */
+  int32_t reserved_enis;
+  /* KubeletConfiguration (nil-able fields: <0 = nil) */
+  int32_t max_pods, pods_per_core;
+  kg_range kube_reserved, system_reserved;     /* pools.quantities */
+  kg_range eviction_hard, eviction_soft;       /* pools.labels: signal name -> value string ("5%", "100Mi") */
+  uint8_t has_eviction_hard, has_eviction_soft;
+  /* EC2NodeClass */
+  uint8_t instance_store_policy_raid0;
+  int64_t root_volume_milli;      /* blockDeviceMappings RootVolume size, <0 = none */
+  int64_t ephemeral_device_volume_milli; /* bdm matching the AMI family's EphemeralBlockDevice, <0 = none */
+  int64_t last_bdm_volume_milli;  /* Custom AMI family: last mapping's size, <0 = none */
+  uint8_t has_block_device_mappings;
+} kg_ec2_catalog_desc;
+
+/* ---------------------------------------------------------------- pods */
+typedef struct {
+  uint32_t topology_key;
+  int32_t max_skew;
+  int32_t min_domains;   /* <0 = nil */
+  uint8_t when_unsatisfiable;
+  kg_selector selector;
+} kg_spread;
+
+typedef struct {
+  uint32_t topology_key;
+  kg_selector selector;
+  kg_range namespaces;   /* pools.req_values; empty -> the pod's own namespace */
+  int32_t weight;        /* preferred terms only */
+} kg_pod_affinity_term;
+
+typedef struct { int32_t weight; kg_range reqs; } kg_weighted_term;
+typedef struct { uint32_t ip /* KG_NONE = 0.0.0.0 */; int32_t port; uint8_t protocol; } kg_host_port;
+
+typedef struct {
+  uint32_t uid, ns;
+  int64_t creation_ts;          /* seconds; Queue tie-break */
+  kg_range labels;              /* pools.labels */
+  kg_range requests;            /* pools.quantities = resources.RequestsForPods WITHOUT the implicit pods:1 */
+  kg_range node_selector;       /* pools.labels */
+  kg_range required_terms;      /* pools.ranges -> each a range of pools.reqs (OR terms) */
+  kg_range preferred_terms;     /* weighted_terms[] */
+  kg_range tolerations;
+  kg_range spreads;             /* spreads[] */
+  kg_range affinity_required, affinity_preferred;       /* affinity_terms[] */
+  kg_range anti_affinity_required, anti_affinity_preferred;
+  kg_range host_ports;
+  /* disruption cost inputs (designs/consolidation.md:25-42) */
+  int32_t priority;
+  int32_t deletion_cost;
+  int32_t node;                 /* bound pods: index into cluster nodes; -1 for pending pods */
+  uint8_t reschedulable;        /* bound pods: counted in candidate.reschedulablePods */
+} kg_pod;
+
+typedef struct {
+  kg_pools pools;
+  const kg_pod* pods;                       uint32_t n_pods;
+  const kg_weighted_term* weighted_terms;   uint32_t n_weighted_terms;
+  const kg_spread* spreads;                 uint32_t n_spreads;
+  const kg_pod_affinity_term* affinity_terms; uint32_t n_affinity_terms;
+  const kg_host_port* host_ports;           uint32_t n_host_ports;
+} kg_pods_desc;
+
+/* ---------------------------------------------------------------- cluster */
+typedef struct {
+  uint32_t name;            /* node name; hostname label falls back to it */
+  kg_range labels;          /* pools.labels (zone, instance-type, capacity-type, nodepool, hostname ...) */
+  kg_range taints;          /* StateNode.Taints() */
+  kg_range available;       /* StateNode.Available(): allocatable - bound pod requests */
+  kg_range capacity;        /* StateNode.Capacity(): charged against NodePool limits */
+  kg_range daemon_requests; /* remaining daemonset requests, already clamped >= 0 */
+  uint8_t initialized, managed, deleting;
+  double price;             /* unused on input; reserved */
+} kg_node;
+
+typedef struct {
+  kg_pods_desc pods;        /* bound pods; pod.node indexes nodes[] */
+  const kg_node* nodes;     uint32_t n_nodes;
+} kg_cluster_desc;
+
+/* ---------------------------------------------------------------- nodepools */
+typedef struct {
+  uint32_t name;
+  int32_t weight;
+  kg_range requirements;    /* pools.reqs (spec.template.spec.requirements, minValues allowed) */
+  kg_range labels;          /* pools.labels (spec.template.metadata.labels) */
+  kg_range taints;          /* spec.template.spec.taints */
+  uint8_t has_limits;
+  kg_range limits;          /* pools.quantities */
+  kg_range daemon_overhead; /* pools.quantities: requests of daemonset pods that fit the template */
+  uint32_t catalog;         /* index into the catalogs[] passed alongside */
+} kg_nodepool;
+
+typedef struct {
+  kg_pools pools;
+  const kg_nodepool* nodepools; uint32_t n_nodepools;
+  kg_range well_known_labels;   /* pools.req_values: karpv1.WellKnownLabels incl. provider additions (labels.go:31-53) */
+  int32_t max_instance_types;   /* 60 (instance.go:54); <=0 disables truncation */
+} kg_nodepools_desc;
+
+/* ---------------------------------------------------------------- results */
+typedef struct {
+  uint32_t nodepool;        /* index into nodepools[] */
+  uint32_t n_pods;
+  kg_range types;           /* into type_ids[]: price-ordered, truncated InstanceTypeOptions (catalog-local indices) */
+  kg_range requirements;    /* into reqs[] */
+  kg_range requests;        /* into quantities[] */
+  uint8_t truncation_failed;/* minValues broke under Truncate: claim dropped by the reference */
+} kg_claim_out;
+
+typedef struct {
+  uint32_t key;             /* offset id into strings (see below) */
+  uint8_t complement;
+  uint8_t has_gt, has_lt;
+  int64_t gt, lt;
+  kg_range values;          /* into value_ids[] */
+} kg_req_out;
+
+/* All arrays are caller-allocated; cap_* are capacities, n_* are filled by the library and
+ * needed_* report the untruncated sizes.  Strings in results are offsets (string index) into
+ * the result's own string blob. */
+typedef struct {
+  /* per pod, in input order */
+  uint8_t* pod_kind;  int32_t* pod_index; uint32_t* pod_reason; uint32_t cap_pods;
+  kg_claim_out* claims;   uint32_t cap_claims, n_claims, needed_claims;
+  uint32_t* type_ids;     uint32_t cap_type_ids, n_type_ids, needed_type_ids;
+  kg_req_out* reqs;       uint32_t cap_reqs, n_reqs, needed_reqs;
+  uint32_t* value_ids;    uint32_t cap_value_ids, n_value_ids, needed_value_ids;
+  kg_quantity* quantities;uint32_t cap_quantities, n_quantities, needed_quantities;
+  char* str_data;         uint32_t cap_str_data, n_str_data, needed_str_data;
+  uint32_t* str_offsets;  uint32_t cap_strs, n_strs, needed_strs;
+  /* counters */
+  uint64_t visited_existing, visited_claims, visited_claim_types, new_claim_scans, relaxations;
+  double algorithmic_bytes; /* SURVEY.md 8(d) definition */
+  double device_ms;         /* HIP-event time of the solve kernel(s) */
+} kg_results;
+
+/* per-pod failure reason bits */
+enum { KG_REASON_TAINTS = 1, KG_REASON_REQUIREMENTS = 2, KG_REASON_TOPOLOGY = 4, KG_REASON_NO_TYPE = 8,
+       KG_REASON_LIMITS = 16, KG_REASON_MIN_VALUES = 32, KG_REASON_RESOURCES = 64, KG_REASON_UNINITIALIZED_NODE = 128 };
+
+typedef struct {
+  int32_t decision;          /* KG_DECISION_* */
+  int32_t n_candidates;      /* candidates in the command (prefix length for multi-node) */
+  int32_t first_candidate;   /* single-node: winning index in the given order; multi: 0 */
+  uint32_t nodepool;         /* replacement claim's nodepool */
+  uint32_t n_types;          /* replacement InstanceTypeOptions, price ordered */
+  uint32_t* type_ids;        uint32_t cap_type_ids;
+  uint8_t replacement_spot_only; /* capacity-type pinned to spot (computeConsolidation tail) */
+  double candidate_price;
+  uint64_t simulations;      /* number of Solve simulations evaluated */
+  double device_ms;
+} kg_decision;
+
+/* per-candidate record (also the fixed-size record gathered across GPUs) */
+typedef struct {
+  int32_t candidate;         /* index in candidates[] (single) or prefix length-1 (multi) */
+  int32_t decision;          /* before first-wins selection */
+  uint32_t nodepool, n_types;
+  double candidate_price;
+  uint64_t type_mask[13];    /* catalog types of the replacement (<= 832 types) after price filters */
+  uint8_t spot_only; uint8_t pad[7];
+} kg_candidate_record;
+
+typedef struct {
+  const int32_t* candidates; uint32_t n_candidates; /* node indices, already in disruption-cost order */
+  uint8_t spot_to_spot_enabled;                     /* FEATURE_GATES=SpotToSpotConsolidation */
+  int32_t shard, n_shards;                          /* this process evaluates units i with i % n_shards == shard */
+} kg_candidates_desc;
+
+typedef struct {
+  uint64_t solves, pods, kernel_launches;
+  double device_ms_total, host_compile_ms_total;
+  uint64_t device_bytes_resident;
+} kg_stats;
+
+typedef struct kg_ctx kg_ctx;
+typedef struct kg_catalog kg_catalog;
+typedef struct kg_cluster kg_cluster;
+
+/* lifecycle.  device < 0 -> current device.  Fails (KG_EDEVICE) when no GPU is present. */
+int32_t kg_init(int32_t device, kg_ctx** out);
+int32_t kg_destroy(kg_ctx* ctx);
+int32_t kg_last_error(kg_ctx* ctx, char* buf, size_t n);
+int32_t kg_stats_get(kg_ctx* ctx, kg_stats* out);
+
+/* catalog: replaces the List() miss path.  `generation` is the cache key of
+ * instancetype.go:127-136 folded to 64 bits; re-upload when it changes. */
+int32_t kg_catalog_upload(kg_ctx* ctx, const kg_catalog_desc* desc, uint64_t generation, kg_catalog** out);
+/* same, starting from raw EC2 facts: does createOfferings + NewInstanceType natively. */
+int32_t kg_catalog_build_ec2(kg_ctx* ctx, const kg_ec2_catalog_desc* desc, uint64_t generation, kg_catalog** out);
+/* read back what the encoder computed for type i (for GetInstanceTypes parity): allocatable
+ * per resource in `names` order, and offering count. */
+int32_t kg_catalog_query(kg_catalog* cat, uint32_t type_index, const char* const* resource_names, uint32_t n,
+                         int64_t* capacity_milli, int64_t* allocatable_milli, char* name_buf, size_t name_cap);
+int32_t kg_catalog_size(kg_catalog* cat, uint32_t* n_types, uint64_t* generation);
+int32_t kg_catalog_free(kg_catalog* cat);
+
+int32_t kg_cluster_upload(kg_ctx* ctx, const kg_cluster_desc* desc, kg_cluster** out);
+int32_t kg_cluster_free(kg_cluster* cl);
+
+/* Scheduler.Solve + Results.TruncateInstanceTypes for one batch of pending pods. */
+int32_t kg_solve(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, kg_cluster* cluster /* may be NULL */,
+                 const kg_pods_desc* pods, const kg_nodepools_desc* nodepools, kg_results* out);
+
+/* InstanceTypes.Truncate(reqs, max) / OrderByPrice for a launch (instance.go:101): orders the
+ * given types by (cheapest compatible available offering price, name) and keeps max_types. */
+int32_t kg_truncate(kg_ctx* ctx, kg_catalog* catalog, const kg_pools* pools, kg_range requirements,
+                    const uint32_t* type_ids, uint32_t n_types, int32_t max_types,
+                    uint32_t* out_type_ids, uint32_t* n_out, uint8_t* min_values_failed);
+
+/* launch-side filters of CloudProvider.Create (cloudprovider.go:267-282, instance.go:95-104):
+ * resolveInstanceTypes -> (no minValues ? filterExotic + filterUnwantedSpot) -> Truncate(60). */
+int32_t kg_launch_filter(kg_ctx* ctx, kg_catalog* catalog, const kg_pools* pools, kg_range requirements,
+                         kg_range requests, int32_t max_types,
+                         uint32_t* out_type_ids, uint32_t cap, uint32_t* n_out, uint8_t* min_values_failed);
+
+/* consolidation: one independent SimulateScheduling per candidate (single) or per prefix (multi).
+ * records[] receives one kg_candidate_record per unit evaluated by this shard (cap_records);
+ * kg_consolidate_select replays the reference's selection over the gathered records. */
+int32_t kg_consolidate_single(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, kg_cluster* cluster,
+                              const kg_pods_desc* pending, const kg_nodepools_desc* nodepools,
+                              const kg_candidates_desc* cands, kg_candidate_record* records, uint32_t cap_records,
+                              uint32_t* n_records, double* device_ms);
+int32_t kg_consolidate_multi(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, kg_cluster* cluster,
+                             const kg_pods_desc* pending, const kg_nodepools_desc* nodepools,
+                             const kg_candidates_desc* cands, kg_candidate_record* records, uint32_t cap_records,
+                             uint32_t* n_records, double* device_ms);
+/* first-wins (single) / binary-search replay (multi) over records gathered from all shards. */
+int32_t kg_consolidate_select(int32_t multi, const kg_candidate_record* records, uint32_t n_records,
+                              uint32_t n_candidates, kg_decision* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KARPGPU_H */
