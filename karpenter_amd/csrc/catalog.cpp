@@ -1,0 +1,183 @@
+// catalog.cpp -- catalog upload: cloudprovider.InstanceType list -> SoA / bitmask tables.
+//
+// Encodes what pkg/providers/instancetype/types.go:56-66 builds (Name, Requirements, Offerings,
+// Capacity, Overhead) into:
+//   alloc/cap [R][T] int64 milli        Allocatable() = Capacity - Overhead.Total()
+//   thr_*   per resource: sorted distinct allocatable values + "types with alloc >= v" masks
+//   cthr_*  per resource: sorted distinct capacity values + "types with cap <= v" masks
+//   twv     per (key, value): types whose requirement on key contains value
+//   kU/kN   per key: types that list the key as DoesNotExist / do not mention it
+//   offmask per (zone, capacity-type): types with an AVAILABLE offering there (instancetype.go:289)
+#include "ctx.hpp"
+
+namespace kg {
+
+static std::vector<uint32_t> vals_of(Vocab& V, const kg_pools& p, uint32_t key, kg_range r) {
+  std::vector<uint32_t> out;
+  for (uint32_t v : kgdesc::values(p, r)) out.push_back(V.val(key, kgdesc::str(p.strings, v)));
+  return out;
+}
+
+HReq parse_req(Vocab& V, const kg_pools& p, const kg_requirement& q) {
+  uint32_t key = V.key(kgdesc::str(p.strings, q.key));
+  return hreq_new(V, key, q.op, vals_of(V, p, key, q.values), q.min_values);
+}
+
+HReqs parse_reqs(Vocab& V, const kg_pools& p, kg_range r) {
+  HReqs out;
+  for (auto& q : kgdesc::reqs(p, r)) out.add(V, parse_req(V, p, q));
+  return out;
+}
+
+std::vector<std::pair<uint32_t, int64_t>> parse_rl(Vocab& V, const kg_pools& p, kg_range r) {
+  std::map<uint32_t, int64_t> m;
+  for (auto& q : kgdesc::quantities(p, r)) m[V.resources.id(kgdesc::str(p.strings, q.name))] += q.milli;
+  return {m.begin(), m.end()};
+}
+
+void parse_catalog(kg_ctx* ctx, const kg_catalog_desc* d, kg_catalog* cat) {
+  Vocab& V = ctx->V;
+  const uint32_t kZone = ctx->kZone, kCT = ctx->kCT, kZid = ctx->kZid;
+  for (uint32_t i = 0; i < d->n_types; ++i) {
+    const kg_instance_type& t = d->types[i];
+    CatType ct;
+    ct.name = std::string(kgdesc::str(d->pools.strings, t.name));
+    ct.reqs = parse_reqs(V, d->pools, t.requirements);
+    for (auto& r : ct.reqs.rs)
+      if (r.compl_) throw Unsupported("instance type requirement with a complement operator");
+    ct.capacity = parse_rl(V, d->pools, t.capacity);
+    ct.overhead = parse_rl(V, d->pools, t.overhead);
+    for (auto& o : kgdesc::span(d->offerings, d->n_offerings, t.offerings, "offering range")) {
+      CatOffering co;
+      co.zone = V.val(kZone, kgdesc::str(d->pools.strings, o.zone));
+      co.ct = V.val(kCT, kgdesc::str(d->pools.strings, o.capacity_type));
+      co.zid = o.zone_id == KG_NONE ? -1 : (int)V.val(kZid, kgdesc::str(d->pools.strings, o.zone_id));
+      co.price = o.price;
+      co.available = o.available != 0;
+      ct.offerings.push_back(co);
+    }
+    cat->types.push_back(std::move(ct));
+  }
+}
+
+// (Re)build the device tables for the context's current resource vocabulary.
+void build_catalog_tables(kg_ctx* ctx, kg_catalog* cat) {
+  Vocab& V = ctx->V;
+  CatalogTables& C = cat->tab;
+  if (C.dev.ptr) { hal::dfree(C.dev.ptr); C.dev.ptr = nullptr; }
+  C = CatalogTables();
+  const uint32_t T = (uint32_t)cat->types.size(), TW = (T + 63) / 64, R = (uint32_t)V.resources.size();
+  C.T = T; C.TW = std::max(TW, 1u); C.R = R;
+  const uint32_t tw = C.TW;
+  C.all_types.assign(tw, 0);
+  for (uint32_t t = 0; t < T; ++t) C.all_types[t >> 6] |= 1ull << (t & 63);
+  std::vector<int64_t> cap((size_t)std::max(R, 1u) * std::max(T, 1u), 0), alloc(cap.size(), 0);
+  for (uint32_t t = 0; t < T; ++t) {
+    for (auto& kv : cat->types[t].capacity) { cap[(size_t)kv.first * T + t] = kv.second; alloc[(size_t)kv.first * T + t] = kv.second; }
+    for (auto& kv : cat->types[t].overhead)
+      // resources.Subtract(Capacity, Overhead.Total()): only keys of Capacity appear in Allocatable
+      for (auto& ck : cat->types[t].capacity) if (ck.first == kv.first) alloc[(size_t)kv.first * T + t] -= kv.second;
+  }
+  std::vector<uint64_t> valid(tw, 0);
+  for (uint32_t t = 0; t < T; ++t) {
+    bool ok = true;
+    for (auto& ck : cat->types[t].capacity) if (alloc[(size_t)ck.first * T + t] < 0) ok = false;
+    if (ok) valid[t >> 6] |= 1ull << (t & 63);
+  }
+  // threshold tables
+  std::vector<int64_t> thr_val, cthr_val;
+  std::vector<uint32_t> thr_off(R + 1, 0), thr_n(std::max(R, 1u), 0), cthr_off(R + 1, 0), cthr_n(std::max(R, 1u), 0);
+  std::vector<uint64_t> thr_mask, cthr_mask;
+  for (uint32_t r = 0; r < R; ++r) {
+    std::vector<int64_t> av(alloc.begin() + (size_t)r * T, alloc.begin() + (size_t)r * T + T), cv(cap.begin() + (size_t)r * T, cap.begin() + (size_t)r * T + T);
+    auto uniq = [](std::vector<int64_t> v) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); return v; };
+    std::vector<int64_t> ua = uniq(av), uc = uniq(cv);
+    thr_off[r] = (uint32_t)thr_val.size(); thr_n[r] = (uint32_t)ua.size();
+    for (int64_t x : ua) {
+      thr_val.push_back(x);
+      size_t base = thr_mask.size();
+      thr_mask.resize(base + tw, 0);
+      for (uint32_t t = 0; t < T; ++t) if (av[t] >= x) thr_mask[base + (t >> 6)] |= 1ull << (t & 63);
+    }
+    cthr_off[r] = (uint32_t)cthr_val.size(); cthr_n[r] = (uint32_t)uc.size();
+    for (int64_t x : uc) {
+      cthr_val.push_back(x);
+      size_t base = cthr_mask.size();
+      cthr_mask.resize(base + tw, 0);
+      for (uint32_t t = 0; t < T; ++t) if (cv[t] <= x) cthr_mask[base + (t >> 6)] |= 1ull << (t & 63);
+    }
+  }
+  // per key value->types masks
+  const uint32_t K = (uint32_t)V.keys.size();
+  C.key_row_off.assign(K, UINT32_MAX);
+  C.key_nvals.assign(K, 0);
+  C.kU.assign(K, std::vector<uint64_t>(tw, 0));
+  C.kN.assign(K, C.all_types);
+  std::vector<uint64_t> twv;
+  std::vector<uint8_t> mentioned(K, 0);
+  for (auto& t : cat->types) for (auto& r : t.reqs.rs) mentioned[r.key] = 1;
+  for (uint32_t k = 0; k < K; ++k) {
+    if (!mentioned[k]) continue;
+    const uint32_t nv = (uint32_t)V.vals[k].size();
+    C.key_row_off[k] = (uint32_t)(twv.size() / tw);
+    C.key_nvals[k] = nv;
+    size_t base = twv.size();
+    twv.resize(base + (size_t)nv * tw, 0);
+    for (uint32_t t = 0; t < T; ++t) {
+      const HReq* r = cat->types[t].reqs.find(k);
+      if (!r) continue;
+      C.kN[k][t >> 6] &= ~(1ull << (t & 63));
+      if (r->vals.empty()) C.kU[k][t >> 6] |= 1ull << (t & 63);
+      for (uint32_t v : r->vals) twv[base + (size_t)v * tw + (t >> 6)] |= 1ull << (t & 63);
+    }
+  }
+  // offerings
+  const uint32_t nz = (uint32_t)V.vals[ctx->kZone].size(), nct = (uint32_t)V.vals[ctx->kCT].size();
+  if (nz > 64 || nct > 4) throw Unsupported("more than 64 zones or 4 capacity types");
+  C.n_zone_vals = nz; C.n_ct_vals = nct;
+  std::vector<uint64_t> offmask((size_t)64 * 4 * tw, 0);
+  std::vector<uint8_t> zone_zid(64, 0xFF);
+  std::vector<uint32_t> off_begin(T + 1, 0);
+  std::vector<uint16_t> off_zone, off_ct, off_zid;
+  std::vector<double> off_price;
+  std::vector<uint8_t> off_avail;
+  for (uint32_t t = 0; t < T; ++t) {
+    off_begin[t] = (uint32_t)off_zone.size();
+    for (auto& o : cat->types[t].offerings) {
+      if (o.available) offmask[((size_t)o.zone * 4 + o.ct) * tw + (t >> 6)] |= 1ull << (t & 63);
+      if (o.zid >= 0) {
+        if (o.zid > 63) throw Unsupported("more than 64 zone ids");
+        if (zone_zid[o.zone] != 0xFF && zone_zid[o.zone] != (uint8_t)o.zid) throw Unsupported("zone with two zone ids");
+        zone_zid[o.zone] = (uint8_t)o.zid;
+      }
+      off_zone.push_back((uint16_t)o.zone); off_ct.push_back((uint16_t)o.ct);
+      off_zid.push_back(o.zid < 0 ? 0xFFFF : (uint16_t)o.zid);
+      off_price.push_back(o.price); off_avail.push_back(o.available);
+    }
+  }
+  off_begin[T] = (uint32_t)off_zone.size();
+  // an offering without zone id next to offerings of the same zone with one would break the zone->zid fold
+  for (uint32_t t = 0; t < T; ++t)
+    for (auto& o : cat->types[t].offerings)
+      if (o.zid < 0 && zone_zid[o.zone] != 0xFF) throw Unsupported("zone id present on some offerings of a zone only");
+  std::vector<uint16_t> name_rank(std::max(T, 1u), 0);
+  {
+    std::vector<uint32_t> idx(T);
+    for (uint32_t t = 0; t < T; ++t) idx[t] = t;
+    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return cat->types[a].name < cat->types[b].name; });
+    for (uint32_t i = 0; i < T; ++i) name_rank[idx[i]] = (uint16_t)i;
+  }
+  Arena& A = C.image;
+  C.o_thr_val = A.add(thr_val); C.o_thr_off = A.add(thr_off); C.o_thr_n = A.add(thr_n); C.o_thr_mask = A.add(thr_mask);
+  C.o_cthr_val = A.add(cthr_val); C.o_cthr_off = A.add(cthr_off); C.o_cthr_n = A.add(cthr_n); C.o_cthr_mask = A.add(cthr_mask);
+  C.o_valid = A.add(valid); C.o_cap = A.add(cap); C.o_alloc = A.add(alloc); C.o_twv = A.add(twv, tw);
+  C.o_offmask = A.add(offmask); C.o_zone_zid = A.add(zone_zid); C.o_name_rank = A.add(name_rank);
+  C.o_off_begin = A.add(off_begin); C.o_off_zone = A.add(off_zone); C.o_off_ct = A.add(off_ct); C.o_off_zid = A.add(off_zid);
+  C.o_off_price = A.add(off_price); C.o_off_avail = A.add(off_avail);
+  C.dev.bytes = A.bytes.size();
+  C.dev.ptr = hal::dmalloc(C.dev.bytes);
+  hal::h2d(C.dev.ptr, A.bytes.data(), C.dev.bytes);
+  ctx->stats.device_bytes_resident += C.dev.bytes;
+}
+
+}  // namespace kg

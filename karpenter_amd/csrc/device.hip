@@ -1,0 +1,101 @@
+// device.hip -- gfx950 kernels and the HIP implementation of hal.hpp.
+#include <hip/hip_runtime.h>
+
+#include <stdexcept>
+#include <string>
+
+#include "hal.hpp"
+
+namespace kg {
+
+// k_type_filter: requirement-set entries x instance types -> T-bit masks (one thread per output word)
+__global__ void __launch_bounds__(256) k_type_filter(DevProblem P, PrepassTables X) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t total = X.E * (uint32_t)P.TW;
+  if (i >= total) return;
+  const uint32_t e = i / P.TW;
+  const int w = (int)(i % P.TW);
+  X.e_amask_out[i] = type_filter_word(P, e, w);
+}
+
+// k_node_static: requirement sets x existing nodes -> N-bit masks.  One wave covers 64 consecutive
+// nodes of one requirement set; the ballot is the output word.
+__global__ void __launch_bounds__(256) k_node_static(DevProblem P, PrepassTables X) {
+  const uint32_t s = blockIdx.y;
+  const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool ok = n < (uint32_t)P.N && node_static_bit(P, X, s, n);
+  const unsigned long long b = __ballot(ok);
+  if ((threadIdx.x & 63) == 0 && (n >> 6) < (uint32_t)P.NW) X.nlab_out[(size_t)s * P.NW + (n >> 6)] = b;
+}
+
+template <int NT, bool STATS>
+__global__ void __launch_bounds__(NT) k_solve(DevProblem P, const SimState* sims, const uint32_t* nqueue) {
+  __shared__ Shared sh;
+  const SimState S = sims[blockIdx.x];
+  solve_block<NT, STATS>(P, S, sh, nqueue[blockIdx.x]);
+}
+
+namespace hal {
+
+static void ck(hipError_t e, const char* what) {
+  if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+std::string init(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) return "no HIP device available (libkarpgpu has no CPU fallback)";
+  if (device >= 0) {
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return std::string("hipSetDevice: ") + hipGetErrorString(e);
+  }
+  return "";
+}
+void* dmalloc(size_t bytes) {
+  void* p = nullptr;
+  ck(hipMalloc(&p, bytes ? bytes : 8), "hipMalloc");
+  return p;
+}
+void dfree(void* p) { if (p) (void)hipFree(p); }
+void h2d(void* dst, const void* src, size_t bytes) { if (bytes) ck(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "hipMemcpy H2D"); }
+void d2h(void* dst, const void* src, size_t bytes) { if (bytes) ck(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost), "hipMemcpy D2H"); }
+void dzero(void* dst, size_t bytes) { if (bytes) ck(hipMemset(dst, 0, bytes), "hipMemset"); }
+
+struct Timer {
+  hipEvent_t a, b;
+  Timer() { ck(hipEventCreate(&a), "event"); ck(hipEventCreate(&b), "event"); ck(hipEventRecord(a, 0), "record"); }
+  float stop() {
+    ck(hipEventRecord(b, 0), "record");
+    ck(hipEventSynchronize(b), "kernel execution");
+    float ms = 0;
+    ck(hipEventElapsedTime(&ms, a, b), "elapsed");
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return ms;
+  }
+};
+
+void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms) {
+  Timer t;
+  const uint32_t total = X.E * (uint32_t)P.TW;
+  if (total) hipLaunchKernelGGL(k_type_filter, dim3((total + 255) / 256), dim3(256), 0, 0, P, X);
+  if (P.N > 0 && P.S > 0) hipLaunchKernelGGL(k_node_static, dim3((P.N + 255) / 256, P.S), dim3(256), 0, 0, P, X);
+  ck(hipGetLastError(), "prepass launch");
+  *ms = t.stop();
+}
+
+void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int block, bool stats, float* ms) {
+  Timer t;
+  if (block >= 1024) {
+    if (stats) hipLaunchKernelGGL((k_solve<1024, true>), dim3(nsims), dim3(1024), 0, 0, P, sims, nqueue);
+    else hipLaunchKernelGGL((k_solve<1024, false>), dim3(nsims), dim3(1024), 0, 0, P, sims, nqueue);
+  } else {
+    if (stats) hipLaunchKernelGGL((k_solve<256, true>), dim3(nsims), dim3(256), 0, 0, P, sims, nqueue);
+    else hipLaunchKernelGGL((k_solve<256, false>), dim3(nsims), dim3(256), 0, 0, P, sims, nqueue);
+  }
+  ck(hipGetLastError(), "solve launch");
+  *ms = t.stop();
+}
+const char* backend() { return "hip-gfx950"; }
+
+}  // namespace hal
+}  // namespace kg

@@ -1,0 +1,41 @@
+// emu.cpp -- TEST-ONLY host emulation of hal.hpp (built with -DKG_EMU into tests/emu; never linked
+// into libkarpgpu.so).  Runs each workgroup as a loop over thread ids so the host compile logic and
+// the kernels' control flow can be debugged without a GPU.
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+
+#include "hal.hpp"
+
+namespace kg::hal {
+std::string init(int) { return ""; }
+void* dmalloc(size_t bytes) { return std::calloc(bytes ? bytes : 8, 1); }
+void dfree(void* p) { std::free(p); }
+void h2d(void* dst, const void* src, size_t bytes) { if (bytes) std::memcpy(dst, src, bytes); }
+void d2h(void* dst, const void* src, size_t bytes) { if (bytes) std::memcpy(dst, src, bytes); }
+void dzero(void* dst, size_t bytes) { if (bytes) std::memset(dst, 0, bytes); }
+
+void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms) {
+  auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t e = 0; e < X.E; ++e)
+    for (int w = 0; w < P.TW; ++w) X.e_amask_out[(size_t)e * P.TW + w] = type_filter_word(P, e, w);
+  for (int s = 0; s < P.S; ++s) {
+    for (int w = 0; w < P.NW; ++w) X.nlab_out[(size_t)s * P.NW + w] = 0;
+    for (int n = 0; n < P.N; ++n)
+      if (node_static_bit(P, X, s, n)) X.nlab_out[(size_t)s * P.NW + (n >> 6)] |= 1ull << (n & 63);
+  }
+  *ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int, bool stats, float* ms) {
+  auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < nsims; ++i) {
+    Shared sh;
+    std::memset(&sh, 0, sizeof sh);
+    if (stats) solve_block<64, true>(P, sims[i], sh, nqueue[i]);
+    else solve_block<64, false>(P, sims[i], sh, nqueue[i]);
+  }
+  *ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+const char* backend() { return "emu"; }
+}  // namespace kg::hal

@@ -1,0 +1,22 @@
+// hal.hpp -- the few device operations the host side needs.  Implemented by device.hip (HIP,
+// product) and by emu.cpp (host loops, TEST-ONLY emulation build).
+#pragma once
+#include <cstddef>
+#include <string>
+
+#include "solve_core.hpp"
+
+namespace kg::hal {
+// returns empty string on success, else the error text
+std::string init(int device);
+void* dmalloc(size_t bytes);
+void dfree(void* p);
+void h2d(void* dst, const void* src, size_t bytes);
+void d2h(void* dst, const void* src, size_t bytes);
+void dzero(void* dst, size_t bytes);
+// k_type_filter + k_node_static
+void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms);
+// one workgroup per simulation; sims = DEVICE array of SimState
+void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue_dev, int block, bool stats, float* ms);
+const char* backend();
+}  // namespace kg::hal

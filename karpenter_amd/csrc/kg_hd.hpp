@@ -1,0 +1,34 @@
+// kg_hd.hpp -- build-mode glue for the solve core.
+//
+// The solve core (solve_core.hpp) is written as block-cooperative phases.  In the product build
+// (hipcc, gfx950) a phase body runs once per thread of the workgroup and phases are separated by
+// __syncthreads().  With -DKG_EMU (g++, TEST-ONLY library tests/emu) the same source runs a
+// workgroup as a host loop over thread ids, so the host compile logic and the kernel's control
+// flow can be debugged with gdb / sanitizers in a container that has no GPU.  The emulation is
+// never part of libkarpgpu.so.
+#pragma once
+#include <cstdint>
+
+#ifdef KG_EMU
+#define KG_HD
+#define KG_DEVICE_ONLY 0
+#define KG_FOR_THREADS(tid, nthreads) for (int tid = 0; tid < (nthreads); ++tid)
+#define KG_SYNC() ((void)0)
+namespace kg {
+inline void atomic_min_u32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
+inline int popc64(uint64_t x) { return __builtin_popcountll(x); }
+inline int ctz64(uint64_t x) { return __builtin_ctzll(x); }
+}  // namespace kg
+#else
+#include <hip/hip_runtime.h>
+#define KG_HD __device__ __forceinline__
+#define KG_DEVICE_ONLY 1
+#define KG_FOR_THREADS(tid, nthreads) for (int tid = (int)threadIdx.x, kg_once_ = 0; kg_once_ == 0; kg_once_ = 1)
+#define KG_SYNC() __syncthreads()
+namespace kg {
+// workgroup-shared (LDS) minimum
+__device__ __forceinline__ void atomic_min_u32(uint32_t* p, uint32_t v) { atomicMin(p, v); }
+__device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
+__device__ __forceinline__ int ctz64(uint64_t x) { return __ffsll((unsigned long long)x) - 1; }
+}  // namespace kg
+#endif

@@ -1,0 +1,269 @@
+"""Synthetic pod / cluster populations for BASELINE.json's configs.
+
+Everything is drawn from splitmix64 with the committed seeds, so the CPU oracle, the device
+path, the tests and bench.py all see identical inputs.  This module only produces plain Python
+problem descriptions (dicts); karpenter_amd.abi turns them into C-ABI descriptors.
+"""
+import json
+import math
+import os
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+MI = 1024 * 1024
+GI = 1024 * MI
+G = "karpenter.k8s.aws"
+L_ZONE = "topology.kubernetes.io/zone"
+L_HOSTNAME = "kubernetes.io/hostname"
+L_CT = "karpenter.sh/capacity-type"
+L_ARCH = "kubernetes.io/arch"
+L_IT = "node.kubernetes.io/instance-type"
+L_NODEPOOL = "karpenter.sh/nodepool"
+
+# karpv1.WellKnownLabels after the provider's init() (pkg/apis/v1/labels.go:29-53)
+WELL_KNOWN_LABELS = [
+    L_NODEPOOL, L_ZONE, "topology.kubernetes.io/region", L_IT, L_ARCH, "kubernetes.io/os", L_CT,
+    "node.kubernetes.io/windows-build",
+    G + "/instance-hypervisor", G + "/instance-encryption-in-transit-supported", G + "/instance-category",
+    G + "/instance-family", G + "/instance-generation", G + "/instance-size", G + "/instance-local-nvme",
+    G + "/instance-cpu", G + "/instance-cpu-manufacturer", G + "/instance-memory", G + "/instance-ebs-bandwidth",
+    G + "/instance-network-bandwidth", G + "/instance-gpu-name", G + "/instance-gpu-manufacturer",
+    G + "/instance-gpu-count", G + "/instance-gpu-memory", G + "/instance-accelerator-name",
+    G + "/instance-accelerator-manufacturer", G + "/instance-accelerator-count", "topology.k8s.aws/zone-id",
+]
+
+_MASK = (1 << 64) - 1
+
+
+class SplitMix64:
+    def __init__(self, seed):
+        self.x = seed & _MASK
+
+    def next(self):
+        self.x = (self.x + 0x9E3779B97F4A7C15) & _MASK
+        z = self.x
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _MASK
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _MASK
+        return z ^ (z >> 31)
+
+    def below(self, n):
+        return self.next() % n
+
+    def uniform(self):
+        return (self.next() >> 11) / float(1 << 53)
+
+    def weighted(self, weights):
+        t = self.below(sum(weights))
+        for i, w in enumerate(weights):
+            if t < w:
+                return i
+            t -= w
+        return len(weights) - 1
+
+    def poisson(self, lam):
+        # Knuth; lam is small here
+        l, k, p = math.exp(-lam), 0, 1.0
+        while True:
+            k += 1
+            p *= self.uniform()
+            if p <= l:
+                return k - 1
+
+
+def _load(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def ec2_facts_776():
+    """EC2 facts for the documented us-east-1 catalog, rebuilt from the data the reference ships:
+    labels of website/.../instance-types.md + zz_generated.vpclimits.go (tests/golden)."""
+    rows, limits = _load("instance_types_doc.json"), _load("vpclimits.json")
+    infos = []
+    for row in rows:
+        lab, name = row["labels"], row["name"]
+        lim = limits.get(name)
+        if lim is None:
+            continue
+        arch = lab["kubernetes.io/arch"]
+        info = {
+            "InstanceType": name,
+            "ProcessorInfo": {"SupportedArchitectures": ["arm64" if arch == "arm64" else "x86_64"]},
+            "VCpuInfo": {"DefaultVCpus": int(lab[G + "/instance-cpu"])},
+            "MemoryInfo": {"SizeInMiB": int(lab[G + "/instance-memory"])},
+            "Hypervisor": lab.get(G + "/instance-hypervisor", ""),
+            "SupportedUsageClasses": ["on-demand", "spot"],
+            "NetworkInfo": {
+                "DefaultNetworkCardIndex": lim["default_card"],
+                "NetworkCards": [{"MaximumNetworkInterfaces": c[0], "NetworkCardIndex": c[1]} for c in lim["cards"]],
+                "Ipv4AddressesPerInterface": lim["ipv4_per_interface"],
+                "EncryptionInTransitSupported": lab.get(G + "/instance-encryption-in-transit-supported") == "true",
+            },
+        }
+        if G + "/instance-cpu-manufacturer" in lab:
+            info["ProcessorInfo"]["Manufacturer"] = lab[G + "/instance-cpu-manufacturer"]
+        if G + "/instance-gpu-count" in lab:
+            man = lab[G + "/instance-gpu-manufacturer"]
+            man = {"nvidia": "NVIDIA", "amd": "AMD", "habana": "Habana"}.get(man, man)
+            info["GpuInfo"] = {"Gpus": [{"Name": lab[G + "/instance-gpu-name"], "Manufacturer": man,
+                                         "Count": int(lab[G + "/instance-gpu-count"]),
+                                         "MemoryInfo": {"SizeInMiB": int(lab[G + "/instance-gpu-memory"])}}]}
+        if G + "/instance-accelerator-count" in lab and not name.startswith("trn1"):
+            info["InferenceAcceleratorInfo"] = {"Accelerators": [{
+                "Name": lab[G + "/instance-accelerator-name"], "Manufacturer": lab[G + "/instance-accelerator-manufacturer"],
+                "Count": int(lab[G + "/instance-accelerator-count"])}]}
+        if G + "/instance-local-nvme" in lab:
+            info["InstanceStorageInfo"] = {"NvmeSupport": "required", "TotalSizeInGB": int(lab[G + "/instance-local-nvme"])}
+        if G + "/instance-ebs-bandwidth" in lab:
+            info["EbsInfo"] = {"EbsOptimizedSupport": "default",
+                               "EbsOptimizedInfo": {"MaximumBandwidthInMbps": int(lab[G + "/instance-ebs-bandwidth"])}}
+        efa = row["resources"].get("vpc.amazonaws.com/efa")
+        if efa is not None:
+            info["NetworkInfo"]["EfaInfo"] = {"MaximumEfaInterfaces": int(efa)}
+        infos.append(info)
+    return infos
+
+
+def ec2_context(zones, ami_family="AL2023", unavailable=()):
+    """Provider state around the catalog: subnets, prices, ICE cache.  Spot price =
+    round(OD * 0.5, 3) per zone (the reference's own test convention, instancetype suite_test.go:2516)."""
+    od = _load("pricing_od.json")["on_demand"]
+    spot = {}
+    for name, p in od.items():
+        for z in zones:
+            spot[(name, z)] = round(p * 0.5, 3)
+    return {
+        "ami_family": ami_family, "region": "us-east-1", "vm_memory_overhead_percent": 0.075, "reserved_enis": 0,
+        "subnets": [{"zone": z, "zone_id": "use1-az%d" % (i + 1)} for i, z in enumerate(zones)],
+        "od_prices": od, "spot_prices": spot, "unavailable": set(unavailable),
+        "limits": _load("vpclimits.json"), "bandwidth": _load("bandwidth.json"),
+        "offering_zones": None,  # None = every type offered in every zone
+    }
+
+
+def zones_n(n):
+    return ["us-east-1" + c for c in "abcdef"[:n]]
+
+
+# ------------------------------------------------------------------------------------ pods
+_CPU = [100, 250, 500, 1000, 2000, 4000, 8000]
+_CPU_W = [20, 20, 20, 15, 10, 10, 5]
+
+
+def mixed_pods(n, seed, zones, families, prefix="pod"):
+    """C2 / C5 mix."""
+    r = SplitMix64(seed)
+    pods = []
+    for i in range(n):
+        cpu = _CPU[r.weighted(_CPU_W)]
+        mem = cpu * [1, 2, 4, 8][r.below(4)] * GI  # milli-bytes: cpu(m) * GiB/core == bytes*1000
+        p = {"uid": "%s-%06d" % (prefix, i), "ns": "default", "creation_ts": 1700000000 + i // 500,
+             "labels": {"app": "mix"}, "requests": {"cpu": cpu, "memory": mem}}
+        if r.below(100) < 2:
+            p["requests"]["nvidia.com/gpu"] = [1, 2, 4, 8][r.below(4)] * 1000
+        sel = {}
+        if r.below(100) < 30:
+            sel[L_ARCH] = "amd64" if r.below(100) < 70 else "arm64"
+        if r.below(100) < 25:
+            sel[L_ZONE] = zones[r.below(len(zones))]
+        if sel:
+            p["node_selector"] = sel
+        term = []
+        if r.below(100) < 20:
+            fams = sorted({families[r.below(len(families))] for _ in range(3)})
+            term.append((G + "/instance-family", "In", fams))
+        if r.below(100) < 10:
+            term.append((G + "/instance-generation", "Gt", ["4"]))
+        if term:
+            p["required_terms"] = [term]
+        pods.append(p)
+    return pods
+
+
+def homogeneous_pods(n, cpu=10, mem=50 * MI * 1000):
+    """C1: identical 10m / 50Mi pods (test/suites/scale/provisioning_test.go:63-68)."""
+    return [{"uid": "pod-%06d" % i, "ns": "default", "creation_ts": 1700000000, "labels": {"app": "inflate"},
+             "requests": {"cpu": cpu, "memory": mem}} for i in range(n)]
+
+
+def spread_pods(n_deployments, replicas, seed):
+    """C3: every deployment spreads over zones (maxSkew 1); 50% add hostname spread; 10% use hostname
+    self-anti-affinity instead."""
+    r = SplitMix64(seed)
+    pods = []
+    for d in range(n_deployments):
+        cpu = _CPU[r.weighted(_CPU_W[:5] + [0, 0])]
+        mem = cpu * [1, 2, 4][r.below(3)] * GI
+        app = "dep-%03d" % d
+        sel = {"match_labels": {"app": app}}
+        mode = r.below(100)
+        spreads = [{"key": L_ZONE, "max_skew": 1, "when": "DoNotSchedule", "selector": sel}]
+        anti = None
+        if mode < 10:
+            anti = [{"key": L_HOSTNAME, "selector": sel}]
+        elif mode < 60:
+            spreads.append({"key": L_HOSTNAME, "max_skew": 1, "when": "DoNotSchedule", "selector": sel})
+        for k in range(replicas):
+            p = {"uid": "%s-%04d" % (app, k), "ns": "default", "creation_ts": 1700000000 + d, "labels": {"app": app},
+                 "requests": {"cpu": cpu, "memory": mem}, "spreads": spreads}
+            if anti:
+                p["anti_affinity_required"] = anti
+            pods.append(p)
+    return pods
+
+
+def default_nodepool(name="default", capacity_types=("on-demand", "spot"), weight=0, limits=None, catalog=0, extra_reqs=()):
+    reqs = [(L_CT, "In", list(capacity_types))] + list(extra_reqs)
+    return {"name": name, "weight": weight, "requirements": reqs, "labels": {}, "taints": [], "limits": limits,
+            "daemon_overhead": {}, "catalog": catalog}
+
+
+def existing_cluster(n_nodes, seed, types, zones, nodepool="default", pods_lambda=12.0, util=0.35):
+    """C4 / C5 existing nodes: type uniform over {large..4xlarge} of m5/c5/r5/m6i/c6i/r6i/m6g/c6g, zone uniform,
+    50/50 spot/on-demand, ~Poisson(pods_lambda) bound pods of 250m-2 CPU at ~util utilisation.
+    `types` = list of catalog type dicts (name, requirements, capacity, overhead)."""
+    r = SplitMix64(seed)
+    fams = {"m5", "c5", "r5", "m6i", "c6i", "r6i", "m6g", "c6g"}
+    sizes = {"large", "xlarge", "2xlarge", "4xlarge"}
+    pool = [t for t in types if t["name"].split(".")[0] in fams and t["name"].split(".")[1] in sizes]
+    nodes, bound = [], []
+    for i in range(n_nodes):
+        t = pool[r.below(len(pool))]
+        zone = zones[r.below(len(zones))]
+        ct = "spot" if r.below(2) == 0 else "on-demand"
+        labels = {}
+        for k, op, vals in t["requirements"]:
+            if op == "In" and len(vals) == 1:
+                labels[k] = vals[0]
+        name = "node-%05d" % i
+        labels.update({L_ZONE: zone, L_CT: ct, L_NODEPOOL: nodepool, L_HOSTNAME: name})
+        alloc = {k: v - t["overhead"].get(k, 0) for k, v in t["capacity"].items()}
+        npods = max(1, r.poisson(pods_lambda))
+        budget_cpu = int(alloc["cpu"] * util)
+        used = {"cpu": 0, "memory": 0, "pods": 0}
+        for k in range(npods):
+            cpu = [250, 500, 1000, 2000][r.below(4)]
+            cpu = min(cpu, max(50, budget_cpu // npods))
+            mem = cpu * [1, 2, 4][r.below(3)] * GI
+            if used["cpu"] + cpu > alloc["cpu"] or used["memory"] + mem > alloc["memory"] or used["pods"] + 1000 > alloc["pods"]:
+                break
+            used["cpu"] += cpu
+            used["memory"] += mem
+            used["pods"] += 1000
+            bound.append({"uid": "%s-p%02d" % (name, k), "ns": "default", "creation_ts": 1690000000 + i,
+                          "labels": {"app": "svc-%02d" % r.below(40)}, "requests": {"cpu": cpu, "memory": mem},
+                          "node": i, "reschedulable": True})
+        avail = {k: v - used.get(k, 0) for k, v in alloc.items()}
+        nodes.append({"name": name, "labels": labels, "taints": [], "available": avail, "capacity": dict(t["capacity"]),
+                      "daemon_requests": {}, "initialized": True, "managed": True, "deleting": False})
+    return nodes, bound
+
+
+def disruption_order(nodes, bound):
+    """Candidates sorted ascending by disruption cost (designs/consolidation.md:25-42) with
+    lifetimeRemaining = 1: cost = sum over pods of clamp(1 + deletionCost/2^27 + priority/2^25, -10, 10).
+    Ties keep node order (stable)."""
+    cost = [0.0] * len(nodes)
+    for p in bound:
+        c = 1.0 + p.get("deletion_cost", 0) / float(2 ** 27) + p.get("priority", 0) / float(2 ** 25)
+        cost[p["node"]] += max(-10.0, min(10.0, c))
+    return sorted(range(len(nodes)), key=lambda i: cost[i])
