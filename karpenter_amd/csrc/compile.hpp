@@ -1,0 +1,72 @@
+// compile.hpp -- host compile of one scheduling problem into device tables.
+//
+// Mirrors what provisioner.NewScheduler / scheduling.NewScheduler / NewTopology assemble before
+// Solve runs: NodePools in weight order with their
+// NodeClaimTemplate requirements, daemon overhead and remaining limits; ExistingNodes in
+// (initialized, name) order; pod requirement sets (NewPodRequirements / NewStrictPodRequirements);
+// the Preferences.Relax chain of each pod as a list of precompiled variants; topology groups with
+// their initial domain counts.
+#pragma once
+#include <set>
+
+#include "ctx.hpp"
+
+namespace kg {
+
+struct PSel {
+  bool nil = false;
+  std::vector<std::pair<uint32_t, uint32_t>> ml;
+  struct Ex { uint32_t key; int op; std::vector<uint32_t> vals; };
+  std::vector<Ex> ex;
+  bool matches(const std::vector<std::pair<uint32_t, uint32_t>>& labels) const;
+  std::string canon() const;
+};
+struct PSpread { uint32_t key; int max_skew, min_domains, when; PSel sel; };
+struct PTerm { uint32_t key; PSel sel; std::vector<uint32_t> ns; int weight; };
+struct PTol { int key; uint32_t value; int op, effect; };
+struct PTaint { uint32_t key, value; int effect; };
+
+struct PodClass {
+  uint32_t ns = 0;
+  std::vector<std::pair<uint32_t, uint32_t>> labels;  // sorted (lab ids)
+  std::vector<HReq> node_selector;
+  std::vector<std::vector<HReq>> required;
+  std::vector<std::pair<int, std::vector<HReq>>> preferred;
+  std::vector<PTol> tols;
+  std::vector<PSpread> spreads;
+  std::vector<PTerm> aff_req, aff_pref, anti_req, anti_pref;
+  bool host_ports = false;
+};
+
+struct PodRef {
+  uint32_t cls;
+  std::vector<std::pair<uint32_t, int64_t>> requests;  // incl. pods:1
+  std::string uid;
+  int64_t creation;
+  int node;
+  bool reschedulable;
+};
+
+struct ParsedPods {
+  std::vector<PodClass> classes;
+  std::vector<PodRef> pods;
+};
+
+void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out);
+
+struct CNode {
+  std::string name;
+  std::vector<std::pair<uint32_t, uint32_t>> labels;  // (global key, value id)
+  std::vector<PTaint> taints;
+  std::vector<std::pair<uint32_t, int64_t>> available, capacity, daemon;
+  bool initialized, managed, deleting;
+  uint32_t hostname_val;  // value id under the hostname key
+};
+
+}  // namespace kg
+
+struct kg_cluster {
+  kg_ctx* ctx;
+  std::vector<kg::CNode> nodes;
+  kg::ParsedPods bound;
+};

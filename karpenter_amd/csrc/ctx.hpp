@@ -1,0 +1,25 @@
+// ctx.hpp -- library context shared by catalog.cpp / karpgpu.cpp.
+#pragma once
+#include <mutex>
+#include <string>
+
+#include "hal.hpp"
+#include "host_model.hpp"
+
+struct kg_ctx {
+  kg::Vocab V;
+  kg::StrMap lab;  // pod-label / namespace / uid strings (selector space, never on the device)
+  std::string last_error;
+  kg_stats stats{};
+  std::mutex mu;
+  uint32_t kHostname, kZone, kCT, kZid, kNodePool, kInstanceType;
+  uint32_t rCPU, rMemory, rPods;
+};
+
+namespace kg {
+HReq parse_req(Vocab& V, const kg_pools& p, const kg_requirement& q);
+HReqs parse_reqs(Vocab& V, const kg_pools& p, kg_range r);
+std::vector<std::pair<uint32_t, int64_t>> parse_rl(Vocab& V, const kg_pools& p, kg_range r);
+void parse_catalog(kg_ctx* ctx, const kg_catalog_desc* d, kg_catalog* cat);
+void build_catalog_tables(kg_ctx* ctx, kg_catalog* cat);
+}  // namespace kg

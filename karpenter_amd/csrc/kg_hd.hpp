@@ -10,7 +10,7 @@
 #include <cstdint>
 
 #ifdef KG_EMU
-#define KG_HD
+#define KG_HD inline
 #define KG_DEVICE_ONLY 0
 #define KG_FOR_THREADS(tid, nthreads) for (int tid = 0; tid < (nthreads); ++tid)
 #define KG_SYNC() ((void)0)

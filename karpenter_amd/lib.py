@@ -1,0 +1,76 @@
+"""Python binding of libkarpgpu's C ABI (include/karpgpu.h) -- the same calls a Go shim makes.
+
+`Library()` loads karpenter_amd/libkarpgpu.so (hipcc, gfx950) and fails loudly when it is
+missing or when no GPU is present: there is no CPU fallback in the product.  Tests that need to
+debug host logic without a GPU pass the path of the TEST-ONLY emulation build explicitly.
+"""
+import ctypes as C
+import os
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_PATH = os.path.join(_HERE, "libkarpgpu.so")
+
+EXPORTS = ["kg_init", "kg_destroy", "kg_last_error", "kg_stats_get", "kg_catalog_upload", "kg_catalog_build_ec2",
+           "kg_catalog_query", "kg_catalog_size", "kg_catalog_free", "kg_cluster_upload", "kg_cluster_free", "kg_solve",
+           "kg_truncate", "kg_launch_filter", "kg_consolidate_single", "kg_consolidate_multi", "kg_consolidate_select"]
+
+
+class KgError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("%s: %s" % (abi.STATUS.get(status, status), msg))
+        self.status = status
+
+
+class Library:
+    def __init__(self, path=None, device=-1):
+        path = path or DEFAULT_PATH
+        if not os.path.exists(path):
+            raise RuntimeError("libkarpgpu.so not built (%s): run __graft_entry__.build()" % path)
+        self.dll = C.CDLL(path)
+        d = self.dll
+        d.kg_init.argtypes = [C.c_int32, C.POINTER(C.c_void_p)]
+        d.kg_last_error.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        d.kg_destroy.argtypes = [C.c_void_p]
+        d.kg_catalog_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+        d.kg_catalog_free.argtypes = [C.c_void_p]
+        d.kg_cluster_upload.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+        d.kg_cluster_free.argtypes = [C.c_void_p]
+        d.kg_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        d.kg_backend.restype = C.c_char_p
+        self.ctx = C.c_void_p()
+        st = d.kg_init(device, C.byref(self.ctx))
+        if st != 0:
+            raise KgError(st, "kg_init failed (no GPU?)")
+
+    def backend(self):
+        return self.dll.kg_backend().decode()
+
+    def _check(self, st):
+        if st != 0:
+            buf = C.create_string_buffer(1024)
+            self.dll.kg_last_error(self.ctx, buf, 1024)
+            raise KgError(st, buf.value.decode())
+
+    def catalog_upload(self, built, generation=1):
+        h = C.c_void_p()
+        self._check(self.dll.kg_catalog_upload(self.ctx, C.addressof(built.desc), generation, C.byref(h)))
+        return h
+
+    def cluster_upload(self, built):
+        h = C.c_void_p()
+        self._check(self.dll.kg_cluster_upload(self.ctx, C.addressof(built.desc), C.byref(h)))
+        return h
+
+    def solve(self, catalogs, cluster, pods, nodepools, n_pods, cap_claims=None):
+        arr = (C.c_void_p * len(catalogs))(*catalogs)
+        rb = abi.ResultBuffers(n_pods, cap_claims)
+        self._check(self.dll.kg_solve(self.ctx, arr, len(catalogs), cluster, C.addressof(pods.desc), C.addressof(nodepools.desc),
+                                      C.addressof(rb.res)))
+        return rb
+
+    def close(self):
+        if self.ctx:
+            self.dll.kg_destroy(self.ctx)
+            self.ctx = C.c_void_p()
