@@ -9,7 +9,9 @@
 #pragma once
 #include <cstdint>
 
-#ifdef KG_EMU
+#if defined(KG_EMU) || !defined(__HIP__)
+// KG_EMU: test-only emulation.  Plain C++ translation units of the product (host compile, C ABI)
+// also land here: they only use the structs and the small meta helpers.
 #define KG_HD inline
 #define KG_DEVICE_ONLY 0
 #define KG_FOR_THREADS(tid, nthreads) for (int tid = 0; tid < (nthreads); ++tid)

@@ -1,0 +1,43 @@
+"""GPU parity: kg_solve through the C ABI of libkarpgpu.so vs the CPU oracle, bit for bit
+(pod -> node/NodeClaim assignment, price-ordered truncated type lists, claim requirements and
+requests, visit counters)."""
+import pytest
+
+from karpenter_amd import lib, workloads as wl
+from tests.helpers import Problem, catalog776, diff_results, families
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    l = lib.Library()
+    assert l.backend() == "hip-gfx950"
+    yield l
+    l.close()
+
+
+def check(L, prob):
+    ro, rg = prob.run_oracle(), prob.run_library(L)
+    d = diff_results(ro.decode(), rg.decode())
+    assert d == "", d
+    assert (ro.res.visited_claims, ro.res.visited_claim_types, ro.res.new_claim_scans, ro.res.visited_existing) == \
+           (rg.res.visited_claims, rg.res.visited_claim_types, rg.res.new_claim_scans, rg.res.visited_existing)
+    return ro, rg
+
+
+def test_c1_homogeneous(L):
+    zones, types = catalog776()
+    check(L, Problem(types, wl.homogeneous_pods(1000), [wl.default_nodepool(capacity_types=("on-demand",))]))
+
+
+@pytest.mark.parametrize("n,seed", [(300, 1), (2000, 42)])
+def test_c2_mixed(L, n, seed):
+    zones, types = catalog776()
+    check(L, Problem(types, wl.mixed_pods(n, seed, zones, families(types)), [wl.default_nodepool()]))
+
+
+def test_c2_full(L):
+    zones, types = catalog776()
+    ro, rg = check(L, Problem(types, wl.mixed_pods(10000, 42, zones, families(types)), [wl.default_nodepool()]))
+    print("C2 full: oracle %.1f ms, device %.2f ms" % (ro.res.device_ms, rg.res.device_ms))
