@@ -726,6 +726,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   // ---- pods
   const int P = (int)PP.pods.size();
   C.P = P;
+  if (P >= (1 << 20)) throw Unsupported("more than 2^20 pods in one solve");
   std::vector<int64_t> preq((size_t)std::max(R, 1) * std::max(P, 1), 0);
   std::vector<uint32_t> pod_variant0(std::max(P, 1), 0), queue0(std::max(P, 1), 0);
   for (int p = 0; p < P; ++p) {
@@ -1001,7 +1002,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   auto sptr = [&](size_t off) { return (uint8_t*)C.state_dev.ptr + off; };
   SimState& St = C.sim;
   St.nreq = (int64_t*)sptr(C.o_nreq); St.c_req = (int64_t*)sptr(C.o_creq); St.c_mask = (uint64_t*)sptr(C.o_cmask); St.c_bits = (uint64_t*)sptr(C.o_cbits);
-  St.c_meta = (uint32_t*)sptr(C.o_cmeta); St.c_npods = (uint32_t*)sptr(C.o_cnpods); St.c_tmpl = (uint16_t*)sptr(C.o_ctmpl); St.order = (uint32_t*)sptr(C.o_order);
+  St.c_meta = (uint32_t*)sptr(C.o_cmeta); St.c_npods = (uint32_t*)sptr(C.o_cnpods); St.c_tmpl = (uint16_t*)sptr(C.o_ctmpl); St.c_stamp = (uint32_t*)sptr(C.o_order);
   St.remaining = (int64_t*)sptr(C.o_remaining); St.gcount = (int32_t*)sptr(C.o_gcount); St.gdom = (uint64_t*)sptr(C.o_gdom); St.gpos = (uint64_t*)sptr(C.o_gpos);
   St.hcount = (int32_t*)sptr(C.o_hcount); St.hpos = (int32_t*)sptr(C.o_hpos); St.queue = (uint32_t*)sptr(C.o_queue); St.last_len = (uint32_t*)sptr(C.o_lastlen);
   St.last_epoch = (uint32_t*)sptr(C.o_lastepoch); St.pod_variant = (uint32_t*)sptr(C.o_podvariant); St.pod_kind = (uint8_t*)sptr(C.o_podkind);
@@ -1261,8 +1262,12 @@ int32_t kg_solve(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, 
   std::vector<uint64_t> c_mask((size_t)TW * nclaims), c_bits((size_t)C->Wa * nclaims);
   std::vector<int64_t> c_req((size_t)R * nclaims);
   if (nclaims) {
-    hal::d2h(order.data(), sp(C->o_order), (size_t)nclaims * 4);
+    std::vector<uint32_t> c_stamp(nclaims);
+    hal::d2h(c_stamp.data(), sp(C->o_order), (size_t)nclaims * 4);
     hal::d2h(c_npods.data(), sp(C->o_cnpods), (size_t)nclaims * 4);
+    // Results.NewNodeClaims comes back in the slice's final (sorted) order
+    for (uint32_t c = 0; c < nclaims; ++c) order[c] = c;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return claim_key(c_npods[a], c_stamp[a], a) < claim_key(c_npods[b], c_stamp[b], b); });
     hal::d2h(c_tmpl.data(), sp(C->o_ctmpl), (size_t)nclaims * 2);
     for (int w = 0; w < TW; ++w) hal::d2h(c_mask.data() + (size_t)w * nclaims, sp(C->o_cmask) + (size_t)w * Cmax * 8, (size_t)nclaims * 8);
     for (int w = 0; w < C->Wa; ++w) hal::d2h(c_bits.data() + (size_t)w * nclaims, sp(C->o_cbits) + (size_t)w * Cmax * 8, (size_t)nclaims * 8);

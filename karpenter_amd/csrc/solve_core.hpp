@@ -143,7 +143,8 @@ struct SimState {
   uint32_t* c_meta;   // [Ka][Cmax]
   uint32_t* c_npods;  // [Cmax]
   uint16_t* c_tmpl;   // [Cmax]
-  uint32_t* order;    // [Cmax] claim ids in scan order (stable by pod count)
+  uint32_t* c_stamp;  // [Cmax] step of the claim's creation / last pod: with c_npods it is the claim's place in the
+                      // reference's (stable) sort.Slice order -- see claim_key()
   int64_t* remaining; // [R][NP]
   int32_t* gcount;    // [G][64]
   uint64_t* gdom;     // [G] registered domains
@@ -163,7 +164,8 @@ struct SimState {
 };
 
 struct Shared {
-  uint32_t pod, variant, best, nclaims, qhead, qlen, epoch, done, placed, fresh_ok, hostname_ctr;
+  uint32_t pod, variant, best, nclaims, qhead, qlen, epoch, done, placed, fresh_ok, hostname_ctr, seq, st_vis;
+  unsigned long long bestkey, st_types;
   uint32_t reason;
   Variant v;
   int64_t preq[KG_MAXR];
@@ -365,6 +367,15 @@ KG_HD void record_host(const SimState& S, const DevProblem& P, const Group& g, u
   int32_t* p = &S.hcount[(size_t)g.hidx * P.H + h];
   if (*p == 0) S.hpos[g.hidx] += 1;
   *p += 1;
+}
+
+// Scan order of in-flight NodeClaims.  The reference re-sorts the slice by len(Pods) before every scan
+// (canonical: stable).  One claim changes between two sorts, so the stable order has a closed form:
+// claims with one pod stay in creation order; a claim that receives its (k+1)-th pod becomes the FIRST
+// of the (k+1)-pod group.  key = pods | (1 pod ? creation step : reversed last-add step) | claim id.
+KG_HD unsigned long long claim_key(uint32_t npods, uint32_t stamp, uint32_t c) {
+  const uint32_t sk = npods <= 1 ? stamp : (0xFFFFFu - stamp);
+  return ((unsigned long long)npods << 40) | ((unsigned long long)(sk & 0xFFFFFu) << 20) | c;
 }
 
 // ------------------------------------------------------------------ NodeClaim.Add for claim c
@@ -712,7 +723,7 @@ template <int NT, bool STATS>
 KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint32_t n_queue) {
   KG_FOR_THREADS(tid, NT) {
     if (tid == 0) {
-      sh.qhead = 0; sh.qlen = n_queue; sh.epoch = 1; sh.nclaims = S.header[0]; sh.done = 0; sh.hostname_ctr = 0;
+      sh.qhead = 0; sh.qlen = n_queue; sh.epoch = 1; sh.nclaims = S.header[0]; sh.done = 0; sh.hostname_ctr = 0; sh.seq = 0;
     }
   }
   KG_SYNC();
@@ -775,57 +786,49 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     if (STATS) {
       KG_FOR_THREADS(tid, NT) { if (tid == 0) S.counters[0] += P.N; }
     }
-    // ---- in-flight NodeClaims in (pod count, stable) order
+    // ---- in-flight NodeClaims: first feasible in (pod count, stable) order = minimum claim_key
+    KG_FOR_THREADS(tid, NT) {
+      if (tid == 0) { sh.bestkey = ~0ull; sh.st_vis = 0; sh.st_types = 0; }
+    }
+    KG_SYNC();
     for (uint32_t base = 0; base < sh.nclaims; base += NT) {
       KG_FOR_THREADS(tid, NT) {
-        const uint32_t pos = base + tid;
-        if (pos < sh.nclaims) {
+        const uint32_t c = base + tid;
+        if (c < sh.nclaims) {
           uint32_t reason = 0, tv = 0;
-          const uint32_t c = S.order[pos];
           const bool ok = eval_claim<false>(P, S, sh, c, false, &reason, &tv);
-          if (ok) atomic_min_u32(&sh.best, pos);
-          if (STATS) S.scratch[(size_t)(P.TW) * P.Cmax + pos] = (reason & ~8u) ? 0 : tv;  // reached the type filter
+          if (ok) atomic_min_u64(&sh.bestkey, claim_key(S.c_npods[c], S.c_stamp[c], c));
+          if (STATS) S.scratch[(size_t)(P.TW) * P.Cmax + c] = (reason & ~(8u | 32u)) ? 0 : tv;  // reached the type filter
         }
       }
-      KG_SYNC();
-      if (sh.best != KG_NOIDX) break;
     }
+    KG_SYNC();
     if (STATS) {
-      KG_FOR_THREADS(tid, NT) {
-        if (tid == 0) {
-          const uint32_t lim = sh.best != KG_NOIDX ? sh.best + 1 : sh.nclaims;
-          S.counters[1] += lim;
-          uint64_t tv = 0;
-          for (uint32_t p = 0; p < lim; ++p) tv += S.scratch[(size_t)(P.TW) * P.Cmax + p];
-          S.counters[2] += tv;
+      // rows the reference visits: every claim up to and including the first feasible one
+      for (uint32_t base = 0; base < sh.nclaims; base += NT) {
+        KG_FOR_THREADS(tid, NT) {
+          const uint32_t c = base + tid;
+          if (c < sh.nclaims && claim_key(S.c_npods[c], S.c_stamp[c], c) <= sh.bestkey) {
+            atomic_add_u32(&sh.st_vis, 1u);
+            atomic_add_u64(&sh.st_types, S.scratch[(size_t)(P.TW) * P.Cmax + c]);
+          }
         }
       }
       KG_SYNC();
+      KG_FOR_THREADS(tid, NT) {
+        if (tid == 0) { S.counters[1] += sh.st_vis; S.counters[2] += sh.st_types; }
+      }
     }
-    if (sh.best != KG_NOIDX) {
+    if (sh.bestkey != ~0ull) {
       KG_FOR_THREADS(tid, NT) {
         if (tid == 0) {
-          const uint32_t pos = sh.best, c = S.order[pos];
+          const uint32_t c = (uint32_t)(sh.bestkey & 0xFFFFFu);
           uint32_t reason = 0, tv = 0;
           eval_claim<true>(P, S, sh, c, false, &reason, &tv);
+          S.c_stamp[c] = ++sh.seq;
           S.pod_kind[sh.pod] = 2;
           S.pod_index[sh.pod] = (int32_t)c;
           sh.placed = 1;
-        }
-      }
-      KG_SYNC();
-      // stable re-sort by pod count: claim at `pos` moves right past every claim with a smaller-or-equal... count
-      // (new count k+1 goes before the first later claim whose count >= k+1)
-      KG_FOR_THREADS(tid, NT) {
-        if (tid == 0) {
-          uint32_t pos = sh.best;
-          const uint32_t c = S.order[pos];
-          const uint32_t cnt = S.c_npods[c];
-          while (pos + 1 < sh.nclaims && S.c_npods[S.order[pos + 1]] < cnt) {
-            S.order[pos] = S.order[pos + 1];
-            pos++;
-          }
-          S.order[pos] = c;
         }
       }
       KG_SYNC();
@@ -896,10 +899,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
                   S.remaining[(size_t)r * P.NP + t] -= mx;
                 }
               }
-              // append; stable order puts a 1-pod claim after every claim with <= 1 pods
-              uint32_t pos = sh.nclaims;
-              while (pos > 0 && S.c_npods[S.order[pos - 1]] > 1) { S.order[pos] = S.order[pos - 1]; pos--; }
-              S.order[pos] = c;
+              S.c_stamp[c] = ++sh.seq;
               sh.nclaims += 1;
               S.pod_kind[sh.pod] = 2;
               S.pod_index[sh.pod] = (int32_t)c;
