@@ -306,7 +306,11 @@ typedef struct {
   /* counters */
   uint64_t visited_existing, visited_claims, visited_claim_types, new_claim_scans, relaxations;
   double algorithmic_bytes; /* SURVEY.md 8(d) definition */
-  double device_ms;         /* HIP-event time of the solve kernel(s) */
+  double device_ms;         /* HIP-event time of all kernels of the call (prepass + solve) */
+  double prepass_ms;        /* k_type_filter + k_node_static */
+  double solve_ms;          /* k_solve (the persistent first-fit kernel) */
+  double host_compile_ms;   /* descriptor parse + requirement compile + table upload */
+  double host_decode_ms;    /* result download + price ordering / truncation + result encode */
 } kg_results;
 
 /* per-pod failure reason bits */

@@ -131,7 +131,8 @@ class Results(C.Structure):
                 ("str_offsets", P), ("cap_strs", C.c_uint32), ("n_strs", C.c_uint32), ("needed_strs", C.c_uint32),
                 ("visited_existing", C.c_uint64), ("visited_claims", C.c_uint64), ("visited_claim_types", C.c_uint64),
                 ("new_claim_scans", C.c_uint64), ("relaxations", C.c_uint64),
-                ("algorithmic_bytes", C.c_double), ("device_ms", C.c_double)]
+                ("algorithmic_bytes", C.c_double), ("device_ms", C.c_double), ("prepass_ms", C.c_double), ("solve_ms", C.c_double),
+                ("host_compile_ms", C.c_double), ("host_decode_ms", C.c_double)]
 
 
 class Decision(C.Structure):

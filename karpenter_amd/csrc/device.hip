@@ -85,13 +85,8 @@ void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms) {
 
 void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int block, bool stats, float* ms) {
   Timer t;
-  if (block >= 1024) {
-    if (stats) hipLaunchKernelGGL((k_solve<1024, true>), dim3(nsims), dim3(1024), 0, 0, P, sims, nqueue);
-    else hipLaunchKernelGGL((k_solve<1024, false>), dim3(nsims), dim3(1024), 0, 0, P, sims, nqueue);
-  } else {
-    if (stats) hipLaunchKernelGGL((k_solve<256, true>), dim3(nsims), dim3(256), 0, 0, P, sims, nqueue);
-    else hipLaunchKernelGGL((k_solve<256, false>), dim3(nsims), dim3(256), 0, 0, P, sims, nqueue);
-  }
+  (void)block; (void)stats;
+  hipLaunchKernelGGL((k_solve<1024, true>), dim3(nsims), dim3(1024), 0, 0, P, sims, nqueue);
   ck(hipGetLastError(), "solve launch");
   *ms = t.stop();
 }

@@ -1378,12 +1378,15 @@ int32_t kg_solve(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, 
   out->relaxations = header[1];
   out->algorithmic_bytes = 212.0 * counters[0] + 400.0 * (counters[1] + counters[3]) + 336.0 * counters[2];
   out->device_ms = ms_pre + ms_solve;
+  out->prepass_ms = ms_pre;
+  out->solve_ms = ms_solve;
   auto t2 = std::chrono::steady_clock::now();
+  out->host_compile_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  out->host_decode_ms = std::chrono::duration<double, std::milli>(t2 - t1).count() - ms_pre - ms_solve;
   ctx->stats.solves += 1;
   ctx->stats.pods += P;
   ctx->stats.device_ms_total += ms_pre + ms_solve;
   ctx->stats.host_compile_ms_total += std::chrono::duration<double, std::milli>(t1 - t0).count();
-  (void)t2;
   return W.overflow ? fail(ctx, KG_ENOMEM, "result buffers too small (see needed_*)") : KG_OK;
   KG_GUARD_END(ctx)
 }

@@ -1,0 +1,40 @@
+"""Host compile + solve-core control flow, debugged without a GPU: the TEST-ONLY emulation build
+(tests/emu/libkarpgpu_emu.so = the product sources compiled with -DKG_EMU, a workgroup run as a host loop) against
+the CPU oracle, bit for bit.  The GPU parity tests proper are tests/test_gpu_*.py (-m gpu)."""
+import os
+
+import pytest
+
+from karpenter_amd import lib, workloads as wl
+from tests.helpers import EMU_PATH, Problem, catalog776, diff_results, families
+
+pytestmark = pytest.mark.skipif(not os.path.exists(EMU_PATH), reason="emulation build missing: run __graft_entry__.build()")
+
+
+@pytest.fixture(scope="module")
+def L():
+    l = lib.Library(EMU_PATH)
+    assert l.backend() == "emu"
+    yield l
+    l.close()
+
+
+def check(L, prob):
+    ro, rg = prob.run_oracle(), prob.run_library(L)
+    d = diff_results(ro.decode(), rg.decode())
+    assert d == "", d
+    assert (ro.res.visited_claims, ro.res.visited_claim_types, ro.res.new_claim_scans, ro.res.visited_existing, ro.res.relaxations) == \
+           (rg.res.visited_claims, rg.res.visited_claim_types, rg.res.new_claim_scans, rg.res.visited_existing, rg.res.relaxations)
+    return ro, rg
+
+
+def test_c1_homogeneous(L):
+    zones, types = catalog776()
+    ro, _ = check(L, Problem(types, wl.homogeneous_pods(1000), [wl.default_nodepool(capacity_types=("on-demand",))]))
+    assert all(k == 2 for k, _ in ro.decode()["pods"])
+
+
+@pytest.mark.parametrize("n,seed", [(0, 1), (1, 1), (300, 1), (1500, 42)])
+def test_c2_mixed(L, n, seed):
+    zones, types = catalog776()
+    check(L, Problem(types, wl.mixed_pods(n, seed, zones, families(types)), [wl.default_nodepool()]))
