@@ -361,6 +361,13 @@ int32_t kg_init(int32_t device, kg_ctx** out);
 int32_t kg_destroy(kg_ctx* ctx);
 int32_t kg_last_error(kg_ctx* ctx, char* buf, size_t n);
 int32_t kg_stats_get(kg_ctx* ctx, kg_stats* out);
+/* kg_results.visited_* / algorithmic_bytes count the rows the REFERENCE algorithm visits.  Keeping them
+ * exact costs one extra pass per placement; production callers switch it off (default: on). */
+int32_t kg_set_collect_stats(kg_ctx* ctx, int32_t enabled);
+/* "hip-gfx950" for the product library */
+const char* kg_backend(void);
+/* sizeof of every element struct of this header, in declaration order (layout check for bindings); returns the count */
+int32_t kg_abi_sizes(uint32_t* out, uint32_t cap);
 
 /* catalog: replaces the List() miss path.  `generation` is the cache key of
  * instancetype.go:127-136 folded to 64 bits; re-upload when it changes. */

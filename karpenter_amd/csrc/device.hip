@@ -28,11 +28,20 @@ __global__ void __launch_bounds__(256) k_node_static(DevProblem P, PrepassTables
   if ((threadIdx.x & 63) == 0 && (n >> 6) < (uint32_t)P.NW) X.nlab_out[(size_t)s * P.NW + (n >> 6)] = b;
 }
 
-template <int NT, bool STATS>
+// k_pod_mask: pod variants x instance types -> the prefilter's per-variant type masks (one thread per output word)
+__global__ void __launch_bounds__(256) k_pod_mask(DevProblem P, PrepassTables X) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t total = (uint32_t)P.NV * (uint32_t)P.TW;
+  if (i >= total) return;
+  X.podmask_out[i] = pod_mask_word(P, i / P.TW, (int)(i % P.TW));
+}
+
+// k_solve: one workgroup = one Scheduler.Solve (persistent over the whole pod queue)
+template <int NT>
 __global__ void __launch_bounds__(NT) k_solve(DevProblem P, const SimState* sims, const uint32_t* nqueue) {
   __shared__ Shared sh;
   const SimState S = sims[blockIdx.x];
-  solve_block<NT, STATS>(P, S, sh, nqueue[blockIdx.x]);
+  solve_block<NT>(P, S, sh, nqueue[blockIdx.x]);
 }
 
 namespace hal {
@@ -79,14 +88,16 @@ void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms) {
   const uint32_t total = X.E * (uint32_t)P.TW;
   if (total) hipLaunchKernelGGL(k_type_filter, dim3((total + 255) / 256), dim3(256), 0, 0, P, X);
   if (P.N > 0 && P.S > 0) hipLaunchKernelGGL(k_node_static, dim3((P.N + 255) / 256, P.S), dim3(256), 0, 0, P, X);
+  const uint32_t pm = (uint32_t)P.NV * (uint32_t)P.TW;
+  if (pm) hipLaunchKernelGGL(k_pod_mask, dim3((pm + 255) / 256), dim3(256), 0, 0, P, X);
   ck(hipGetLastError(), "prepass launch");
   *ms = t.stop();
 }
 
-void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int block, bool stats, float* ms) {
+void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int block, float* ms) {
   Timer t;
-  (void)block; (void)stats;
-  hipLaunchKernelGGL((k_solve<1024, true>), dim3(nsims), dim3(1024), 0, 0, P, sims, nqueue);
+  if (block >= 1024) hipLaunchKernelGGL((k_solve<1024>), dim3(nsims), dim3(1024), 0, 0, P, sims, nqueue);
+  else hipLaunchKernelGGL((k_solve<256>), dim3(nsims), dim3(256), 0, 0, P, sims, nqueue);
   ck(hipGetLastError(), "solve launch");
   *ms = t.stop();
 }

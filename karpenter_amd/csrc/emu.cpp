@@ -24,16 +24,18 @@ void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms) {
     for (int n = 0; n < P.N; ++n)
       if (node_static_bit(P, X, s, n)) X.nlab_out[(size_t)s * P.NW + (n >> 6)] |= 1ull << (n & 63);
   }
+  for (int vi = 0; vi < P.NV; ++vi)
+    for (int w = 0; w < P.TW; ++w) X.podmask_out[(size_t)vi * P.TW + w] = pod_mask_word(P, (uint32_t)vi, w);
   *ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
-void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int, bool stats, float* ms) {
+void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int block, float* ms) {
   auto t0 = std::chrono::steady_clock::now();
   for (int i = 0; i < nsims; ++i) {
-    Shared sh;
+    static Shared sh;
     std::memset(&sh, 0, sizeof sh);
-    if (stats) solve_block<64, true>(P, sims[i], sh, nqueue[i]);
-    else solve_block<64, false>(P, sims[i], sh, nqueue[i]);
+    if (block >= 1024) solve_block<1024>(P, sims[i], sh, nqueue[i]);
+    else solve_block<256>(P, sims[i], sh, nqueue[i]);
   }
   *ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }

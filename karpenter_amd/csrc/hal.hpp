@@ -14,9 +14,9 @@ void dfree(void* p);
 void h2d(void* dst, const void* src, size_t bytes);
 void d2h(void* dst, const void* src, size_t bytes);
 void dzero(void* dst, size_t bytes);
-// k_type_filter + k_node_static
+// k_type_filter + k_node_static + k_pod_mask
 void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms);
 // one workgroup per simulation; sims = DEVICE array of SimState
-void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue_dev, int block, bool stats, float* ms);
+void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue_dev, int block, float* ms);
 const char* backend();
 }  // namespace kg::hal

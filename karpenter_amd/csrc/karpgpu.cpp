@@ -264,13 +264,14 @@ struct Compiled {
   std::vector<int8_t> slot2spec;
   std::vector<uint8_t> spec_slot;
   std::vector<HReqs> reqsets;        // WITH hostname entries (identity)
+  std::vector<uint32_t> act_res;     // active resource -> global resource id
   int R = 0, Ka = 0, Wa = 0, P = 0, N = 0, G = 0, GH = 0, Cmax = 0, TW = 0, T = 0, NP = 0, S = 0;
   DevProblem dp{};
   PrepassTables pre{};
   DeviceBuffer prob_dev, state_dev, sims_dev;
   SimState sim{};  // device pointers
   std::vector<uint8_t> state_image;
-  size_t o_nreq, o_creq, o_cmask, o_cbits, o_cmeta, o_cnpods, o_ctmpl, o_order, o_remaining, o_gcount, o_gdom, o_gpos, o_hcount, o_hpos, o_queue,
+  size_t o_nreq, o_creq, o_chead, o_chstamp, o_cmask, o_cbits, o_cmeta, o_cnpods, o_ctmpl, o_order, o_remaining, o_gcount, o_gdom, o_gpos, o_hcount, o_hpos, o_queue,
       o_lastlen, o_lastepoch, o_podvariant, o_podkind, o_podindex, o_podreason, o_scratch, o_header, o_counters, o_nqueue;
   ~Compiled() {
     hal::dfree(prob_dev.ptr);
@@ -659,10 +660,24 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
 
   // ---- resources and catalog tables
   // intern every resource name first, then make sure the catalog tables cover them
-  const int R = (int)V.resources.size();
-  if (R > KG_MAXR) throw Unsupported("more than 16 resource names");
+  // active resources: requested by a pending pod, part of a template's daemon overhead, or named by a limit.
+  // Everything else can never decide a placement (Fits only looks at requested resources).
+  const int RG = (int)V.resources.size();
+  std::vector<int> ract(RG, -1);
+  {
+    std::vector<uint8_t> used(RG, 0);
+    for (auto& pr : in.pending->pods) for (auto& kv : pr.requests) if (kv.second != 0) used[kv.first] = 1;
+    for (auto& tp : C.templates) {
+      for (auto& kv : tp.daemon) if (kv.second != 0) used[kv.first] = 1;
+      if (tp.has_limits) for (auto& kv : tp.limits) used[kv.first] = 1;
+    }
+    used[ctx->rCPU] = used[ctx->rMemory] = used[ctx->rPods] = 1;
+    for (int r = 0; r < RG; ++r) if (used[r]) { ract[r] = (int)C.act_res.size(); C.act_res.push_back((uint32_t)r); }
+  }
+  const int R = (int)C.act_res.size();
+  if (R > KG_MAXR) throw Unsupported("more than 8 distinct resources requested / limited in one solve");
   C.R = R;
-  if (in.cat->tab.R != (uint32_t)R || in.cat->tab.key_row_off.size() != V.keys.size() || !in.cat->tab.dev.ptr) build_catalog_tables(ctx, in.cat);
+  if (in.cat->tab.R != (uint32_t)RG || in.cat->tab.key_row_off.size() != V.keys.size() || !in.cat->tab.dev.ptr) build_catalog_tables(ctx, in.cat);
   const CatalogTables& CT = in.cat->tab;
   const int T = (int)CT.T, TW = (int)CT.TW;
   C.T = T; C.TW = TW;
@@ -730,16 +745,17 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   std::vector<int64_t> preq((size_t)std::max(R, 1) * std::max(P, 1), 0);
   std::vector<uint32_t> pod_variant0(std::max(P, 1), 0), queue0(std::max(P, 1), 0);
   for (int p = 0; p < P; ++p) {
-    for (auto& kv : PP.pods[p].requests) preq[(size_t)kv.first * P + p] = kv.second;
+    for (auto& kv : PP.pods[p].requests) if (ract[kv.first] >= 0) preq[(size_t)p * R + ract[kv.first]] = kv.second;
     pod_variant0[p] = class_variant0[PP.pods[p].cls];
     queue0[p] = (uint32_t)p;
   }
   {
-    const int64_t* cpu = preq.data() + (size_t)ctx->rCPU * P;
-    const int64_t* mem = preq.data() + (size_t)ctx->rMemory * P;
+    const int rc = ract[ctx->rCPU], rm = ract[ctx->rMemory];
+    auto cpu = [&](uint32_t i) { return preq[(size_t)i * R + rc]; };
+    auto mem = [&](uint32_t i) { return preq[(size_t)i * R + rm]; };
     std::stable_sort(queue0.begin(), queue0.begin() + P, [&](uint32_t a, uint32_t b) {
-      if (cpu[a] != cpu[b]) return cpu[a] > cpu[b];
-      if (mem[a] != mem[b]) return mem[a] > mem[b];
+      if (cpu(a) != cpu(b)) return cpu(a) > cpu(b);
+      if (mem(a) != mem(b)) return mem(a) > mem(b);
       if (PP.pods[a].creation != PP.pods[b].creation) return PP.pods[a].creation < PP.pods[b].creation;
       return PP.pods[a].uid < PP.pods[b].uid;
     });
@@ -753,9 +769,9 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   std::vector<uint8_t> minv_slot;
   for (int t = 0; t < NP; ++t) {
     const Template& tp = C.templates[t];
-    for (auto& kv : tp.daemon) tmpl_req[(size_t)kv.first * NP + t] = kv.second;
+    for (auto& kv : tp.daemon) if (ract[kv.first] >= 0) tmpl_req[(size_t)ract[kv.first] * NP + t] = kv.second;
     tmpl_has_limits[t] = tp.has_limits && !tp.limits.empty();
-    for (auto& kv : tp.limits) { tmpl_limits0[(size_t)kv.first * NP + t] = kv.second; tmpl_limit_res[(size_t)kv.first * NP + t] = 1; }
+    if (tmpl_has_limits[t]) for (auto& kv : tp.limits) { tmpl_limits0[(size_t)ract[kv.first] * NP + t] = kv.second; tmpl_limit_res[(size_t)ract[kv.first] * NP + t] = 1; }
     for (size_t ts = 0; ts < tolsets.size(); ++ts) if (tolerates(tp.taints, tolsets[ts])) tol_tmpl[ts] |= 1ull << t;
     tmpl_minv_off[t] = (uint32_t)minv_slot.size();
     for (auto& q : tp.reqs.rs) {
@@ -773,7 +789,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     for (int t = 0; t < NP; ++t) {
       if (V.vals[ctx->kNodePool].strs[npv] != C.templates[t].name || !tmpl_has_limits[t]) continue;
       for (auto& kv : nodes[n]->capacity)
-        if (tmpl_limit_res[(size_t)kv.first * NP + t]) tmpl_limits0[(size_t)kv.first * NP + t] -= kv.second;
+        if (ract[kv.first] >= 0 && tmpl_limit_res[(size_t)ract[kv.first] * NP + t]) tmpl_limits0[(size_t)ract[kv.first] * NP + t] -= kv.second;
     }
   }
 
@@ -784,9 +800,13 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   for (int n = 0; n < N; ++n) {
     const CNode& nd = *nodes[n];
     bool valid = true;
-    for (auto& kv : nd.available) { navail[(size_t)kv.first * N + n] = kv.second; if (kv.second < 0) valid = false; }
-    for (auto& kv : nd.daemon) nreq0[(size_t)kv.first * N + n] = kv.second;
-    for (int r = 0; r < R; ++r) if (nreq0[(size_t)r * N + n] > navail[(size_t)r * N + n]) valid = false;
+    for (auto& kv : nd.available) { if (ract[kv.first] >= 0) navail[(size_t)ract[kv.first] * N + n] = kv.second; if (kv.second < 0) valid = false; }
+    for (auto& kv : nd.daemon) {
+      if (ract[kv.first] >= 0) nreq0[(size_t)ract[kv.first] * N + n] = kv.second;
+      int64_t av = 0;
+      for (auto& a : nd.available) if (a.first == kv.first) av = a.second;
+      if (kv.second > av) valid = false;
+    }
     for (auto& kv : nd.labels) {
       int a = find_slot(C, kv.first);
       if (a < 0) continue;
@@ -913,6 +933,44 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     for (size_t i = 0; i < idx.size() && idx[i] < 64; ++i) vrank[sp * 64 + idx[i]] = (uint16_t)i;
   }
 
+  // ---- one precompiled record per pod variant (what NodeClaim.Add / ExistingNode.Add need of the pod)
+  const int NV = (int)variants.size();
+  std::vector<VariantCtx> vctx(std::max(NV, 1));
+  for (int vi = 0; vi < NV; ++vi) {
+    VariantCtx& vc = vctx[vi];
+    std::memset(&vc, 0, sizeof vc);
+    vc.v = variants[vi];
+    const uint32_t rs = vc.v.rs;
+    vc.ne = rs_off[rs + 1] - rs_off[rs];
+    uint32_t used = 0;
+    for (uint32_t j = 0; j < vc.ne; ++j) {
+      const uint32_t e = rs_off[rs] + j;
+      PodEntry& pe = vc.ent[j];
+      pe.e = e;
+      pe.meta = e_meta[e];
+      pe.slot = e_slot[e];
+      pe.aoff = C.aoff[pe.slot];
+      pe.w = (uint8_t)C.aw[pe.slot];
+      pe.spec = C.slot2spec[pe.slot];
+      bool anyb = false;
+      for (int i = 0; i < pe.w; ++i) anyb |= rs_bits[e_bits[e] + i] != 0;
+      pe.opc = (uint8_t)opclass(pe.meta & RM_COMPL, anyb);
+      if (used + pe.w <= (uint32_t)KG_EBITS) {
+        pe.bits = (uint16_t)used;
+        for (int i = 0; i < pe.w; ++i) vc.ebits[used + i] = rs_bits[e_bits[e] + i];
+        used += pe.w;
+      } else {
+        pe.bits = 0xFFFF;
+      }
+    }
+    if (vc.v.match_cnt > (uint32_t)KG_MAXLIST) throw Unsupported("pod consults more than 8 topology groups");
+    vc.nlist = vc.v.match_cnt;
+    for (uint32_t li = 0; li < vc.nlist; ++li) {
+      vc.lst[li].le = lists[vc.v.match_off + li];
+      vc.lst[li].g = dgroups[vc.lst[li].le.g];
+    }
+  }
+
   // ---- per-slot catalog views
   std::vector<uint64_t> kU((size_t)std::max(Ka, 1) * TW, 0), kN((size_t)std::max(Ka, 1) * TW, 0);
   std::vector<uint32_t> ktwv_off(std::max(Ka, 1), 0);
@@ -929,7 +987,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
                o_ktoff = A.add(ktwv_off), o_ktn = A.add(ktwv_n), o_vrank = A.add(vrank), o_bnd = A.add(bnd_off), o_gtval = A.add(gtval),
                o_ltval = A.add(ltval), o_gtmask = A.add(gtmask), o_ltmask = A.add(ltmask), o_bmo = A.add(bndmask_off), o_rsoff = A.add(rs_off),
                o_eslot = A.add(e_slot), o_emeta = A.add(e_meta), o_ebits = A.add(e_bits), o_rsbits = A.add(rs_bits),
-               o_amask = A.reserve((size_t)std::max(E, 1u) * TW * 8), o_variants = A.add(variants), o_pv0 = A.add(pod_variant0), o_preq = A.add(preq),
+               o_amask = A.reserve((size_t)std::max(E, 1u) * TW * 8), o_vctx = A.add(vctx), o_podmask = A.reserve((size_t)std::max(NV, 1) * TW * 8), o_pv0 = A.add(pod_variant0), o_preq = A.add(preq),
                o_queue0 = A.add(queue0), o_lists = A.add(lists), o_tmplrs = A.add(tmpl_rs), o_tmplreq = A.add(tmpl_req),
                o_thl = A.add(tmpl_has_limits), o_tl0 = A.add(tmpl_limits0), o_tlr = A.add(tmpl_limit_res), o_toltmpl = A.add(tol_tmpl),
                o_minvoff = A.add(tmpl_minv_off), o_minvslot = A.add(minv_slot), o_minvmin = A.add(minv_min), o_navail = A.add(navail),
@@ -941,6 +999,18 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   auto dptr = [&](size_t off) { return (uint8_t*)C.prob_dev.ptr + off; };
   auto cptr = [&](size_t off) { return (uint8_t*)CT.dev.ptr + off; };
   DevProblem& D = C.dp;
+  int TWP = 16;
+  while (TWP < TW) TWP *= 2;
+  if (TWP > 256) throw Unsupported("more than 16384 instance types");
+  D.TWP = TWP; D.NV = NV; D.stats = stats ? 1 : 0;
+  for (int r = 0; r < R; ++r) {
+    const uint32_t g = C.act_res[r];
+    const uint32_t* toff = (const uint32_t*)(CT.image.bytes.data() + CT.o_thr_off);
+    const uint32_t* tn = (const uint32_t*)(CT.image.bytes.data() + CT.o_thr_n);
+    const uint32_t* coff = (const uint32_t*)(CT.image.bytes.data() + CT.o_cthr_off);
+    const uint32_t* cn = (const uint32_t*)(CT.image.bytes.data() + CT.o_cthr_n);
+    D.a_res[r] = g; D.a_thr_off[r] = toff[g]; D.a_thr_n[r] = tn[g]; D.a_cthr_off[r] = coff[g]; D.a_cthr_n[r] = cn[g];
+  }
   D.R = R; D.Ka = Ka; D.Wa = C.Wa; D.T = T; D.TW = TW; D.NP = NP; D.N = N; D.NW = NW; D.P = P; D.S = S; D.G = G; D.GH = GH; D.H = H;
   D.Cmax = Cmax; D.nspec = nspec; D.NL = (int)lists.size();
   D.slot_zone = spec_of_key(ctx->kZone); D.slot_ct = spec_of_key(ctx->kCT); D.slot_zid = spec_of_key(ctx->kZid);
@@ -952,21 +1022,20 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   D.ltval = (const int64_t*)dptr(o_ltval); D.gtmask = (const uint64_t*)dptr(o_gtmask); D.ltmask = (const uint64_t*)dptr(o_ltmask);
   D.bndmask_off = (const uint32_t*)dptr(o_bmo); D.rs_off = (const uint32_t*)dptr(o_rsoff); D.e_slot = (const uint8_t*)dptr(o_eslot);
   D.e_meta = (const uint32_t*)dptr(o_emeta); D.e_bits = (const uint32_t*)dptr(o_ebits); D.rs_bits = (const uint64_t*)dptr(o_rsbits);
-  D.e_amask = (const uint64_t*)dptr(o_amask); D.variants = (const Variant*)dptr(o_variants); D.pod_variant0 = (const uint32_t*)dptr(o_pv0);
+  D.e_amask = (const uint64_t*)dptr(o_amask); D.vctx = (const VariantCtx*)dptr(o_vctx); D.podmask = (const uint64_t*)dptr(o_podmask); D.pod_variant0 = (const uint32_t*)dptr(o_pv0);
   D.preq = (const int64_t*)dptr(o_preq); D.queue0 = (const uint32_t*)dptr(o_queue0); D.lists = (const ListEntry*)dptr(o_lists);
   D.tmpl_rs = (const uint32_t*)dptr(o_tmplrs); D.tmpl_req = (const int64_t*)dptr(o_tmplreq); D.tmpl_has_limits = (const uint8_t*)dptr(o_thl);
   D.tmpl_limits0 = (const int64_t*)dptr(o_tl0); D.tmpl_limit_res = (const uint8_t*)dptr(o_tlr); D.tol_tmpl = (const uint64_t*)dptr(o_toltmpl);
   D.tmpl_minv_off = (const uint32_t*)dptr(o_minvoff); D.minv_slot = (const uint8_t*)dptr(o_minvslot); D.minv_min = (const uint32_t*)dptr(o_minvmin);
-  D.thr_val = (const int64_t*)cptr(CT.o_thr_val); D.thr_off = (const uint32_t*)cptr(CT.o_thr_off); D.thr_n = (const uint32_t*)cptr(CT.o_thr_n);
-  D.thr_mask = (const uint64_t*)cptr(CT.o_thr_mask); D.cthr_val = (const int64_t*)cptr(CT.o_cthr_val); D.cthr_off = (const uint32_t*)cptr(CT.o_cthr_off);
-  D.cthr_n = (const uint32_t*)cptr(CT.o_cthr_n); D.cthr_mask = (const uint64_t*)cptr(CT.o_cthr_mask); D.valid_types = (const uint64_t*)cptr(CT.o_valid);
-  D.cap = (const int64_t*)cptr(CT.o_cap); D.offmask = (const uint64_t*)cptr(CT.o_offmask); D.zone_zid = (const uint8_t*)cptr(CT.o_zone_zid);
+  D.thr_val = (const int64_t*)cptr(CT.o_thr_val); D.thr_mask = (const uint64_t*)cptr(CT.o_thr_mask);
+  D.cthr_val = (const int64_t*)cptr(CT.o_cthr_val); D.cthr_mask = (const uint64_t*)cptr(CT.o_cthr_mask); D.valid_types = (const uint64_t*)cptr(CT.o_valid);
+  D.cap = (const int64_t*)cptr(CT.o_cap); D.alloc = (const int64_t*)cptr(CT.o_alloc); D.offmask = (const uint64_t*)cptr(CT.o_offmask); D.zone_zid = (const uint8_t*)cptr(CT.o_zone_zid);
   D.n_zone_vals = (int)CT.n_zone_vals; D.n_ct_vals = (int)CT.n_ct_vals;
   D.navail = (const int64_t*)dptr(o_navail); D.nlab = (const uint64_t*)dptr(o_nlab); D.ntol = (const uint64_t*)dptr(o_ntol);
   D.ndom = (const uint16_t*)dptr(o_ndom); D.groups = (const Group*)dptr(o_groups); D.filters = (const uint32_t*)dptr(o_filters);
   PrepassTables& X = C.pre;
   X.E = E; X.nval = (const uint16_t*)dptr(o_nval); X.rs_host_meta = (const uint32_t*)dptr(o_rhm); X.rs_host_off = (const uint32_t*)dptr(o_rho);
-  X.rs_host_nodes = (const uint32_t*)dptr(o_rhn); X.e_amask_out = (uint64_t*)dptr(o_amask); X.nlab_out = (uint64_t*)dptr(o_nlab);
+  X.rs_host_nodes = (const uint32_t*)dptr(o_rhn); X.e_amask_out = (uint64_t*)dptr(o_amask); X.nlab_out = (uint64_t*)dptr(o_nlab); X.podmask_out = (uint64_t*)dptr(o_podmask);
 
   // ---- simulation state image
   Arena SA;
@@ -975,6 +1044,8 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   std::vector<uint64_t> counters(8, 0);
   C.o_nreq = SA.add(nreq0);
   C.o_creq = SA.reserve((size_t)std::max(R, 1) * Cmax * 8);
+  C.o_chead = SA.reserve((size_t)std::max(R, 1) * Cmax * 8);
+  C.o_chstamp = SA.reserve((size_t)Cmax * 4);
   C.o_cmask = SA.reserve((size_t)TW * Cmax * 8);
   C.o_cbits = SA.reserve((size_t)C.Wa * Cmax * 8);
   C.o_cmeta = SA.reserve((size_t)std::max(Ka, 1) * Cmax * 4);
@@ -1001,7 +1072,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   hal::h2d(C.state_dev.ptr, SA.bytes.data(), C.state_dev.bytes);
   auto sptr = [&](size_t off) { return (uint8_t*)C.state_dev.ptr + off; };
   SimState& St = C.sim;
-  St.nreq = (int64_t*)sptr(C.o_nreq); St.c_req = (int64_t*)sptr(C.o_creq); St.c_mask = (uint64_t*)sptr(C.o_cmask); St.c_bits = (uint64_t*)sptr(C.o_cbits);
+  St.nreq = (int64_t*)sptr(C.o_nreq); St.c_req = (int64_t*)sptr(C.o_creq); St.c_head = (int64_t*)sptr(C.o_chead); St.c_hstamp = (uint32_t*)sptr(C.o_chstamp); St.c_mask = (uint64_t*)sptr(C.o_cmask); St.c_bits = (uint64_t*)sptr(C.o_cbits);
   St.c_meta = (uint32_t*)sptr(C.o_cmeta); St.c_npods = (uint32_t*)sptr(C.o_cnpods); St.c_tmpl = (uint16_t*)sptr(C.o_ctmpl); St.c_stamp = (uint32_t*)sptr(C.o_order);
   St.remaining = (int64_t*)sptr(C.o_remaining); St.gcount = (int32_t*)sptr(C.o_gcount); St.gdom = (uint64_t*)sptr(C.o_gdom); St.gpos = (uint64_t*)sptr(C.o_gpos);
   St.hcount = (int32_t*)sptr(C.o_hcount); St.hpos = (int32_t*)sptr(C.o_hpos); St.queue = (uint32_t*)sptr(C.o_queue); St.last_len = (uint32_t*)sptr(C.o_lastlen);
@@ -1011,7 +1082,6 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   C.sims_dev.bytes = sizeof(SimState);
   C.sims_dev.ptr = hal::dmalloc(sizeof(SimState));
   hal::h2d(C.sims_dev.ptr, &St, sizeof(SimState));
-  (void)stats;
   return Cp;
 }
 
@@ -1120,6 +1190,13 @@ int32_t kg_stats_get(kg_ctx* ctx, kg_stats* out) {
 }
 
 const char* kg_backend(void) { return hal::backend(); }
+
+int32_t kg_set_collect_stats(kg_ctx* ctx, int32_t enabled) {
+  if (!ctx) return KG_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->collect_stats = enabled != 0;
+  return KG_OK;
+}
 
 // sizeof of every element struct, in the order karpenter_amd/abi.py lists them (layout check for bindings)
 int32_t kg_abi_sizes(uint32_t* out, uint32_t cap) {
@@ -1237,12 +1314,12 @@ int32_t kg_solve(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, 
   parse_pods(ctx, pods, &pending);
   check(out->cap_pods >= pending.pods.size(), "pod result capacity");
   SolveInputs in{ctx, catalogs[0], cluster, nodepools, &pending};
-  const bool stats = true;
+  const bool stats = ctx->collect_stats;
   auto C = compile_problem(in, stats);
   auto t1 = std::chrono::steady_clock::now();
   float ms_pre = 0, ms_solve = 0;
   hal::launch_prepass(C->dp, C->pre, &ms_pre);
-  hal::launch_solve(C->dp, (const SimState*)C->sims_dev.ptr, 1, (const uint32_t*)((uint8_t*)C->state_dev.ptr + C->o_nqueue), 1024, stats, &ms_solve);
+  hal::launch_solve(C->dp, (const SimState*)C->sims_dev.ptr, 1, (const uint32_t*)((uint8_t*)C->state_dev.ptr + C->o_nqueue), 1024, &ms_solve);
   ctx->stats.kernel_launches += 3;
   // ---- results
   const int P = C->P, Cmax = C->Cmax, TW = C->TW, R = C->R, Ka = C->Ka;
@@ -1267,7 +1344,12 @@ int32_t kg_solve(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, 
     hal::d2h(c_npods.data(), sp(C->o_cnpods), (size_t)nclaims * 4);
     // Results.NewNodeClaims comes back in the slice's final (sorted) order
     for (uint32_t c = 0; c < nclaims; ++c) order[c] = c;
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return claim_key(c_npods[a], c_stamp[a], a) < claim_key(c_npods[b], c_stamp[b], b); });
+    // ... as of the last sort.Slice: the claim touched after it keeps its old place (or stays appended at the end)
+    auto okey = [&](uint32_t c) -> unsigned long long {
+      if (c == header[2]) return header[5] ? ~0ull : claim_key(header[3], header[4], c);
+      return claim_key(c_npods[c], c_stamp[c], c);
+    };
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return okey(a) < okey(b); });
     hal::d2h(c_tmpl.data(), sp(C->o_ctmpl), (size_t)nclaims * 2);
     for (int w = 0; w < TW; ++w) hal::d2h(c_mask.data() + (size_t)w * nclaims, sp(C->o_cmask) + (size_t)w * Cmax * 8, (size_t)nclaims * 8);
     for (int w = 0; w < C->Wa; ++w) hal::d2h(c_bits.data() + (size_t)w * nclaims, sp(C->o_cbits) + (size_t)w * Cmax * 8, (size_t)nclaims * 8);
@@ -1354,7 +1436,7 @@ int32_t kg_solve(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, 
     co.requirements.count = (uint32_t)tmp.size();
     for (auto& q : tmp) W.add_req(q);
     std::vector<std::pair<std::string, int64_t>> rq;
-    for (int r = 0; r < R; ++r) if (c_req[(size_t)r * nclaims + c] != 0) rq.push_back({V.resources.strs[r], c_req[(size_t)r * nclaims + c]});
+    for (int r = 0; r < R; ++r) if (c_req[(size_t)r * nclaims + c] != 0) rq.push_back({V.resources.strs[C->act_res[r]], c_req[(size_t)r * nclaims + c]});
     std::sort(rq.begin(), rq.end());
     co.requests.begin = out->needed_quantities;
     co.requests.count = (uint32_t)rq.size();

@@ -8,24 +8,33 @@
 // Design (DESIGN.md has the long form):
 //   * FFD is a chain of dependent placements, so ONE workgroup owns one Solve and keeps all of
 //     its mutable state; parallelism is across the rows a placement must visit (thread per
-//     existing node / per in-flight NodeClaim) and, for consolidation, across simulations
-//     (workgroup per simulation).  Nothing crosses a CU inside a Solve, so the only barrier is
-//     the workgroup barrier.
+//     existing node / per in-flight NodeClaim / per 64-type word of a NodeClaim's option mask)
+//     and, for consolidation, across simulations (workgroup per simulation).  Nothing crosses a
+//     CU inside a Solve, so the only barrier is the workgroup barrier.
 //   * Everything is a bitset over a vocabulary compiled on the host: requirement value sets per
 //     label key, and -- the part that removes the per-type inner loop -- instance types
 //     themselves: each NodeClaim carries a T-bit "remaining types" mask, and "compatible",
-//     "fits" and "hasOffering" become ANDs with precomputed type masks (per requirement-set
+//     "fits" and "hasOffering" become ANDs with precomputed type masks (per requirement-entry
 //     masks from k_type_filter, per-resource threshold masks, per-(zone,capacity-type)
 //     offering masks).  first-feasible-index = min over feasible rows in scan order.
+//   * One placement = (1) pop + one coalesced load of the pod's precompiled VariantCtx into LDS,
+//     (2) a streaming prefilter over all in-flight NodeClaims (thread per claim; conservative:
+//     toleration bit, per-resource headroom, option mask AND the pod's own type mask),
+//     (3) the exact NodeClaim.Add on the survivors in scan order, 16 threads per survivor (one per
+//     64-type word), (4) commit of the winner.
 #pragma once
 #include "kg_hd.hpp"
 
 namespace kg {
 
-constexpr int KG_MAXR = 16;     // resources
+constexpr int KG_MAXR = 8;      // active resources in one solve (requested by a pod, daemon overhead, or limited)
 constexpr int KG_MAXKA = 32;    // active label keys in one solve
 constexpr int KG_MAXE = 8;      // entries (keys) per requirement set
 constexpr int KG_MAXSPEC = 6;   // "special" 1-word keys: zone, capacity-type, zone-id, os + topology keys
+constexpr int KG_MAXLIST = 8;   // topology groups consulted for one pod
+constexpr int KG_EBITS = 32;    // requirement-value words of one pod staged in LDS
+constexpr int KG_THR_LDS = 1024;  // fit-threshold values staged in LDS
+constexpr int KG_MAXSURV = 1024;  // prefilter survivors handled per round
 constexpr uint32_t KG_NOIDX = 0xFFFFFFFFu;
 
 // requirement meta word
@@ -69,12 +78,39 @@ struct Group {
   uint32_t filter_off, filter_cnt;  // nodeFilter requirement sets (spread only; cnt 0 = always matches)
 };
 
+// One pod requirement entry, precompiled (what NodeClaim.Add needs of it, without pointer chasing)
+struct PodEntry {
+  uint32_t e;      // global entry index (row of e_amask)
+  uint32_t meta;
+  uint16_t aoff;   // word offset of the slot in a claim's requirement row
+  uint16_t bits;   // word offset into VariantCtx::ebits, 0xFFFF = read rs_bits[e_bits[e]]
+  uint8_t slot;
+  int8_t spec;     // special index or -1
+  uint8_t w;       // words of the slot
+  uint8_t opc;     // operator class of the entry
+};
+struct ListX {
+  ListEntry le;
+  Group g;
+};
+// Everything one pod variant brings to a placement; one coalesced load per Queue.Pop.
+struct VariantCtx {
+  Variant v;
+  uint32_t ne, nlist;
+  PodEntry ent[KG_MAXE];
+  ListX lst[KG_MAXLIST];
+  uint64_t ebits[KG_EBITS];
+};
+static_assert(sizeof(VariantCtx) % 8 == 0, "VariantCtx is copied as 64-bit words");
+
 // Read-only problem tables (device pointers).
 struct DevProblem {
-  int R, Ka, Wa, T, TW, NP, N, NW, P, S, G, GH, H, Cmax, nspec, NL;
+  int R, Ka, Wa, T, TW, TWP, NP, N, NW, P, S, G, GH, H, Cmax, nspec, NL, NV;
   int slot_zone, slot_ct, slot_zid;  // special indices (sp) or -1
   uint32_t well_known_slots;         // bit per active slot
-  int res_pr;                        // unused
+  uint32_t stats;                    // 1 = maintain the reference-visit counters (exact, slower)
+  // active resources -> rows of the catalog's per-resource tables
+  uint32_t a_thr_off[KG_MAXR], a_thr_n[KG_MAXR], a_cthr_off[KG_MAXR], a_cthr_n[KG_MAXR], a_res[KG_MAXR];
   // active keys
   const uint16_t* aoff;   // [Ka] word offset of the slot in a requirement row
   const uint16_t* aw;     // [Ka] words
@@ -101,9 +137,10 @@ struct DevProblem {
   const uint64_t* rs_bits;
   const uint64_t* e_amask;  // [E][TW] k_type_filter output: types whose value satisfies the entry (| kN)
   // variants / pods
-  const Variant* variants;
+  const VariantCtx* vctx;       // [NV]
+  const uint64_t* podmask;      // [NV][TW] k_pod_mask output: types the pod's own requirements can ever accept
   const uint32_t* pod_variant0; // [P]
-  const int64_t* preq;          // [R][P]
+  const int64_t* preq;          // [P][R]
   const uint32_t* queue0;       // [P] pods in Queue order
   const ListEntry* lists;
   // templates (nodepools in weight order)
@@ -116,11 +153,12 @@ struct DevProblem {
   const uint32_t* tmpl_minv_off;// [NP+1] minValues entries
   const uint8_t* minv_slot;     // slot
   const uint32_t* minv_min;     // minimum
-  // catalog tables
-  const int64_t* thr_val; const uint32_t* thr_off; const uint32_t* thr_n; const uint64_t* thr_mask;  // alloc >= v
-  const int64_t* cthr_val; const uint32_t* cthr_off; const uint32_t* cthr_n; const uint64_t* cthr_mask; // cap <= v
+  // catalog tables (rows indexed by GLOBAL resource id; use a_* for the active ones)
+  const int64_t* thr_val; const uint64_t* thr_mask;    // alloc >= v
+  const int64_t* cthr_val; const uint64_t* cthr_mask;  // cap <= v
   const uint64_t* valid_types;  // [TW]
-  const int64_t* cap;           // [R][T]
+  const int64_t* cap;           // [RG][T]
+  const int64_t* alloc;         // [RG][T]
   const uint64_t* offmask;      // [64 zones][4 cts][TW] (dense over value ids of the zone / ct slots)
   const uint8_t* zone_zid;      // [64] zone value id -> zone-id value id, 0xFF none
   int n_zone_vals, n_ct_vals;
@@ -138,11 +176,13 @@ struct DevProblem {
 struct SimState {
   int64_t* nreq;      // [R][N]
   int64_t* c_req;     // [R][Cmax]
+  int64_t* c_head;    // [R][Cmax] upper bound of what the claim can still take: max allocatable over its options - c_req
   uint64_t* c_mask;   // [TW][Cmax]
   uint64_t* c_bits;   // [Wa][Cmax]
   uint32_t* c_meta;   // [Ka][Cmax]
   uint32_t* c_npods;  // [Cmax]
   uint16_t* c_tmpl;   // [Cmax]
+  uint32_t* c_hstamp; // [Cmax] c_stamp at the last exact recomputation of c_head
   uint32_t* c_stamp;  // [Cmax] step of the claim's creation / last pod: with c_npods it is the claim's place in the
                       // reference's (stable) sort.Slice order -- see claim_key()
   int64_t* remaining; // [R][NP]
@@ -158,19 +198,29 @@ struct SimState {
   uint8_t* pod_kind;  // [P]
   int32_t* pod_index; // [P]
   uint32_t* pod_reason; // [P]
-  uint64_t* scratch;  // [TW][Cmax] minValues second pass
-  uint32_t* header;   // [16]: 0 nclaims, 1 relaxations, 2..: counters
+  uint64_t* scratch;  // [TW+1][Cmax] candidate option masks of the survivors; row TW: per-claim visit statistic
+  uint32_t* header;   // [16]: 0 nclaims, 1 relaxations, 2-5 the claim touched after the last sort (id, old pods, old stamp, new)
   uint64_t* counters; // [8]: visited_existing, visited_claims, visited_claim_types, new_claim_scans
 };
 
 struct Shared {
-  uint32_t pod, variant, best, nclaims, qhead, qlen, epoch, done, placed, fresh_ok, hostname_ctr, seq, st_vis;
+  uint32_t pod, variant, best, nclaims, qhead, qlen, epoch, done, placed, hostname_ctr, seq, st_vis, reason;
+  uint32_t last_c, last_npods, last_stamp, last_new;  // the one claim touched since the reference's last sort.Slice
+  uint32_t nsurv, scan_base, pass_lo, winner, thr_lds, fresh_lim, fresh_any, fresh_ok;
   unsigned long long bestkey, st_types;
-  uint32_t reason;
-  Variant v;
   int64_t preq[KG_MAXR];
-  int npr;
-  uint8_t pr_res[KG_MAXR];
+  VariantCtx vc;
+  // small problem tables
+  uint16_t aoff[KG_MAXKA], aw[KG_MAXKA];
+  int8_t slot2spec[KG_MAXKA];
+  uint8_t spec_slot[KG_MAXSPEC + 2];
+  uint32_t thr_base[KG_MAXR];
+  int64_t thr_val[KG_THR_LDS];
+  // prefilter survivors of the current round
+  uint32_t surv[KG_MAXSURV];             // claim ids, in arrival order
+  unsigned long long skey[KG_MAXSURV];   // their scan-order keys
+  uint32_t sorted[KG_MAXSURV];           // claim ids in scan order
+  uint32_t sfeas[KG_MAXSURV / 16 + 1];   // per evaluation group of the current pass: some option remains
 };
 
 // ------------------------------------------------------------------ requirement algebra
@@ -212,23 +262,21 @@ KG_HD SReq intersect1(const DevProblem& P, int a, SReq x, SReq y) {
   return r;
 }
 
-// Generic (multi-word) intersection summary of claim slot `a` of claim c with entry e.
-// Returns merged meta; *any = merged has any value bit; optionally writes merged bits.
+// Generic (multi-word) intersection summary of claim slot `a` (w words at row offset off) of claim c with
+// a requirement (pm, pb).  Returns merged meta; *any = merged has any value bit; optionally writes merged bits.
 template <bool WRITE>
-KG_HD uint32_t intersect_claim_entry(const DevProblem& P, const SimState& S, int a, uint32_t c, uint32_t cm, uint32_t e, bool* any,
-                                     bool* changed) {
-  const int w = P.aw[a], off = P.aoff[a];
-  const uint32_t pm = P.e_meta[e];
-  const uint64_t* pb = P.rs_bits + P.e_bits[e];
+KG_HD uint32_t intersect_claim_bits(const DevProblem& P, const SimState& S, int a, int w, int off, uint32_t c, uint32_t cm, uint32_t pm,
+                                    const uint64_t* pb, bool* any, bool* changed, bool* cany) {
   bool xc = cm & RM_COMPL, yc = pm & RM_COMPL;
   uint32_t gt = rm_gt(cm) > rm_gt(pm) ? rm_gt(cm) : rm_gt(pm);
   uint32_t lt = min_nz(rm_lt(cm), rm_lt(pm));
   bool dne = gt && lt && P.gtval[P.bnd_off[a] + gt - 1] >= P.ltval[P.bnd_off[a] + lt - 1];
   bool c2 = xc && yc && !dne;
   uint32_t meta = c2 ? rm_make(true, gt, lt) : rm_make(false, 0, 0);
-  bool anyb = false, chg = meta != cm;
+  bool anyb = false, chg = meta != cm, canyb = false;
   for (int i = 0; i < w; ++i) {
     uint64_t x = S.c_bits[(size_t)(off + i) * P.Cmax + c], y = pb[i];
+    canyb |= x != 0;
     uint64_t r = dne ? 0 : ((xc && yc) ? (x | y) : (xc ? (y & ~x) : (yc ? (x & ~y) : (x & y))));
     if (!dne && gt) r &= P.gtmask[P.bndmask_off[a] + (size_t)(gt - 1) * w + i];
     if (!dne && lt) r &= P.ltmask[P.bndmask_off[a] + (size_t)(lt - 1) * w + i];
@@ -239,6 +287,7 @@ KG_HD uint32_t intersect_claim_entry(const DevProblem& P, const SimState& S, int
   if (WRITE) S.c_meta[(size_t)a * P.Cmax + c] = meta;
   *any = anyb;
   *changed = chg;
+  *cany = canyb;
   return meta;
 }
 
@@ -256,10 +305,8 @@ KG_HD bool claim_compatible_rs(const DevProblem& P, const SimState& S, uint32_t 
       if (!((P.well_known_slots >> a) & 1) && !op_neg(pop)) return false;
       continue;
     }
-    bool canyb = false;
-    for (int i = 0; i < P.aw[a]; ++i) canyb |= S.c_bits[(size_t)(P.aoff[a] + i) * P.Cmax + c] != 0;
-    bool anyb, chg;
-    uint32_t mm = intersect_claim_entry<false>(P, S, a, c, cm, e, &anyb, &chg);
+    bool anyb, chg, canyb;
+    uint32_t mm = intersect_claim_bits<false>(P, S, a, P.aw[a], P.aoff[a], c, cm, pm, pb, &anyb, &chg, &canyb);
     bool empty = !(mm & RM_COMPL) && !anyb;
     if (empty && !(op_neg(pop) && op_neg(opclass(cm & RM_COMPL, canyb)))) return false;
   }
@@ -378,80 +425,90 @@ KG_HD unsigned long long claim_key(uint32_t npods, uint32_t stamp, uint32_t c) {
   return ((unsigned long long)npods << 40) | ((unsigned long long)(sk & 0xFFFFFu) << 20) | c;
 }
 
-// ------------------------------------------------------------------ NodeClaim.Add for claim c
+// ------------------------------------------------------------------ NodeClaim.Add, split for (claim, word) threads
+// Result of the scalar steps of NodeClaim.Add for (pod, claim): requirement merge, topology, requests.
+struct ClaimCtx {
+  uint32_t tmpl, t0, nt;
+  SReq sp[KG_MAXSPEC];
+  uint32_t sp_changed, sp_dne_ok, ent_dne_ok, ent_changed;  // bit per special slot / per pod entry
+  int64_t newreq[KG_MAXR];
+  int32_t thr_idx[KG_MAXR];
+  uint32_t thr_use;  // bit per active resource
+  uint64_t zmask, ctmask;
+  bool off_use, minv, fresh;
+};
+
+KG_HD const uint64_t* entry_bits(const DevProblem& P, const Shared& sh, const PodEntry& pe) {
+  return pe.bits != 0xFFFF ? sh.vc.ebits + pe.bits : P.rs_bits + P.e_bits[pe.e];
+}
+
+// Steps 1-5 of NodeClaim.Add (taints, Compatible + Add of the pod requirements, topology, requests).
 // fresh: the claim was just materialised from its template (all template keys still to be applied).
-// Returns true when the pod fits; with COMMIT also updates the claim.
+// Returns true when the pod reaches the instance-type filter; with COMMIT also updates the claim's requirements.
 template <bool COMMIT>
-KG_HD bool eval_claim(const DevProblem& P, const SimState& S, const Shared& sh, uint32_t c, bool fresh, uint32_t* reason,
-                      uint32_t* types_visited) {
-  const Variant& v = sh.v;
+KG_HD bool claim_prepare(const DevProblem& P, const SimState& S, const Shared& sh, uint32_t c, bool fresh, ClaimCtx& x, uint32_t* reason) {
+  const Variant& v = sh.vc.v;
   const uint32_t tmpl = S.c_tmpl[c];
+  x.tmpl = tmpl;
+  x.fresh = fresh;
   if (!((P.tol_tmpl[v.tolset] >> tmpl) & 1)) { *reason |= 1; return false; }
   if (!v.host_claim_ok) { *reason |= 2; return false; }
-  const uint32_t e0 = P.rs_off[v.rs], ne = P.rs_off[v.rs + 1] - e0;
-  const uint32_t t0 = P.rs_off[P.tmpl_rs[tmpl]], nt = P.rs_off[P.tmpl_rs[tmpl] + 1] - t0;
+  const uint32_t ne = sh.vc.ne;
+  x.t0 = 0; x.nt = 0;
+  if (fresh) { x.t0 = P.rs_off[P.tmpl_rs[tmpl]]; x.nt = P.rs_off[P.tmpl_rs[tmpl] + 1] - x.t0; }
+  x.sp_changed = 0; x.sp_dne_ok = 0; x.ent_dne_ok = 0; x.ent_changed = 0;
 
   // merged view of the special (1-word) slots: start from the claim's own state
-  SReq sp[KG_MAXSPEC];
-  bool sp_changed[KG_MAXSPEC];
-  bool sp_dne_ok[KG_MAXSPEC];
 #pragma unroll
   for (int i = 0; i < KG_MAXSPEC; ++i) {
-    sp[i].meta = 0; sp[i].word = 0; sp_changed[i] = false; sp_dne_ok[i] = false;
+    x.sp[i].meta = 0; x.sp[i].word = 0;
     if (i < P.nspec) {
-      int a = P.spec_slot[i];
-      sp[i].meta = S.c_meta[(size_t)a * P.Cmax + c];
-      sp[i].word = (sp[i].meta & RM_PRESENT) ? S.c_bits[(size_t)P.aoff[a] * P.Cmax + c] : 0;
-      sp_changed[i] = fresh && (sp[i].meta & RM_PRESENT);
+      const int a = sh.spec_slot[i];
+      x.sp[i].meta = S.c_meta[(size_t)a * P.Cmax + c];
+      x.sp[i].word = (x.sp[i].meta & RM_PRESENT) ? S.c_bits[(size_t)sh.aoff[a] * P.Cmax + c] : 0;
+      if (fresh && (x.sp[i].meta & RM_PRESENT)) x.sp_changed |= 1u << i;
     }
   }
   // step A: Requirements.Compatible(podReqs) + Add, entry by entry
-  bool ent_dne_ok[KG_MAXE];  // merged operator in {NotIn, DoesNotExist}
-  bool ent_changed[KG_MAXE];
 #pragma unroll
   for (int j = 0; j < KG_MAXE; ++j) {
-    ent_dne_ok[j] = false; ent_changed[j] = false;
     if ((uint32_t)j < ne) {
-      const uint32_t e = e0 + j;
-      const int a = P.e_slot[e];
-      const uint32_t pm = P.e_meta[e];
-      const uint64_t* pb = P.rs_bits + P.e_bits[e];
-      const int w = P.aw[a];
-      bool panyb = false;
-      for (int i = 0; i < w; ++i) panyb |= pb[i] != 0;
-      const int pop = opclass(pm & RM_COMPL, panyb);
+      const PodEntry pe = sh.vc.ent[j];
+      const int a = pe.slot;
+      const uint32_t pm = pe.meta;
+      const uint64_t* pb = entry_bits(P, sh, pe);
+      const int w = pe.w;
+      const int pop = pe.opc;
       const uint32_t cm = S.c_meta[(size_t)a * P.Cmax + c];
-      const int spi = P.slot2spec[a];
+      const int spi = pe.spec;
       if (!(cm & RM_PRESENT)) {
         if (!((P.well_known_slots >> a) & 1) && !op_neg(pop)) { *reason |= 2; return false; }
-        ent_dne_ok[j] = op_neg(pop);
-        ent_changed[j] = true;
+        if (op_neg(pop)) x.ent_dne_ok |= 1u << j;
+        x.ent_changed |= 1u << j;
         if (spi >= 0) {
 #pragma unroll
-          for (int i = 0; i < KG_MAXSPEC; ++i) if (i == spi) { sp[i].meta = pm; sp[i].word = pb[0]; sp_changed[i] = true; }
+          for (int i = 0; i < KG_MAXSPEC; ++i) if (i == spi) { x.sp[i].meta = pm; x.sp[i].word = pb[0]; x.sp_changed |= 1u << i; }
         }
         if (COMMIT) {
-          for (int i = 0; i < w; ++i) S.c_bits[(size_t)(P.aoff[a] + i) * P.Cmax + c] = pb[i];
+          for (int i = 0; i < w; ++i) S.c_bits[(size_t)(pe.aoff + i) * P.Cmax + c] = pb[i];
           S.c_meta[(size_t)a * P.Cmax + c] = pm;
         }
       } else {
-        bool canyb = false;
-        for (int i = 0; i < w; ++i) canyb |= S.c_bits[(size_t)(P.aoff[a] + i) * P.Cmax + c] != 0;
+        bool anyb, chg, canyb;
+        const uint32_t mm = intersect_claim_bits<COMMIT>(P, S, a, w, pe.aoff, c, cm, pm, pb, &anyb, &chg, &canyb);
         const int cop = opclass(cm & RM_COMPL, canyb);
-        bool anyb, chg;
-        const uint32_t mm = intersect_claim_entry<COMMIT>(P, S, a, c, cm, e, &anyb, &chg);
         const bool empty = !(mm & RM_COMPL) && !anyb;
         if (empty && !(op_neg(pop) && op_neg(cop))) { *reason |= 2; return false; }
-        ent_dne_ok[j] = op_neg(opclass(mm & RM_COMPL, anyb));
-        ent_changed[j] = chg || fresh;
+        if (op_neg(opclass(mm & RM_COMPL, anyb))) x.ent_dne_ok |= 1u << j;
+        if (chg || fresh) x.ent_changed |= 1u << j;
         if (spi >= 0) {
 #pragma unroll
           for (int i = 0; i < KG_MAXSPEC; ++i)
             if (i == spi) {
-              SReq x{cm, sp[i].word}, y{pm, pb[0]};
-              SReq r = intersect1(P, a, x, y);
-              sp_changed[i] = sp_changed[i] || r.word != sp[i].word || r.meta != sp[i].meta;
-              sp[i] = r;
+              SReq xx{cm, x.sp[i].word}, y{pm, pb[0]};
+              SReq r = intersect1(P, a, xx, y);
+              if (r.word != x.sp[i].word || r.meta != x.sp[i].meta) x.sp_changed |= 1u << i;
+              x.sp[i] = r;
             }
         }
       }
@@ -459,14 +516,14 @@ KG_HD bool eval_claim(const DevProblem& P, const SimState& S, const Shared& sh, 
   }
   // step B: Topology.AddRequirements -> Compatible -> Add
   const uint32_t hslot = P.N + c;
-  if (v.match_cnt) {
+  if (sh.vc.nlist) {
     uint64_t topo[KG_MAXSPEC];
-    bool has_topo[KG_MAXSPEC];
+    uint32_t has_topo = 0;
 #pragma unroll
-    for (int i = 0; i < KG_MAXSPEC; ++i) { topo[i] = ~0ull; has_topo[i] = false; }
-    for (uint32_t li = 0; li < v.match_cnt; ++li) {
-      const ListEntry le = P.lists[v.match_off + li];
-      const Group g = P.groups[le.g];
+    for (int i = 0; i < KG_MAXSPEC; ++i) topo[i] = ~0ull;
+    for (uint32_t li = 0; li < sh.vc.nlist; ++li) {
+      const ListEntry le = sh.vc.lst[li].le;
+      const Group g = sh.vc.lst[li].g;
       const bool self = le.flags & LF_SELF;
       if (g.spec == 0xFF) {
         if (!topo_host(S, P, g, self, hslot)) { *reason |= 4; return false; }
@@ -475,215 +532,229 @@ KG_HD bool eval_claim(const DevProblem& P, const SimState& S, const Shared& sh, 
       uint64_t podDom = ((uint64_t)le.poddom_hi << 32) | le.poddom_lo;
       uint64_t nodeDom = ~0ull;
 #pragma unroll
-      for (int i = 0; i < KG_MAXSPEC; ++i) if (i == g.spec) nodeDom = has_mask1(P, P.spec_slot[i], sp[i]);
+      for (int i = 0; i < KG_MAXSPEC; ++i) if (i == g.spec) nodeDom = has_mask1(P, sh.spec_slot[i], x.sp[i]);
       TopoOut o = topo_small(P, S, g, le.g, self, podDom, nodeDom);
       if (!o.ok) { *reason |= 4; return false; }
 #pragma unroll
-      for (int i = 0; i < KG_MAXSPEC; ++i) if (i == g.spec) { topo[i] &= o.opts; has_topo[i] = true; }
+      for (int i = 0; i < KG_MAXSPEC; ++i) if (i == g.spec) { topo[i] &= o.opts; has_topo |= 1u << i; }
     }
 #pragma unroll
     for (int i = 0; i < KG_MAXSPEC; ++i) {
-      if (i < P.nspec && has_topo[i]) {
-        const int a = P.spec_slot[i];
+      if (i < P.nspec && ((has_topo >> i) & 1)) {
+        const int a = sh.spec_slot[i];
         SReq inc{rm_make(false, 0, 0), topo[i]};
-        if (!(sp[i].meta & RM_PRESENT)) {
+        if (!(x.sp[i].meta & RM_PRESENT)) {
           // receiver lacks the key: allowed when well-known or the incoming operator is DoesNotExist
           if (!((P.well_known_slots >> a) & 1) && topo[i] != 0) { *reason |= 4; return false; }
-          sp[i] = inc;
-          sp_changed[i] = true;
+          x.sp[i] = inc;
+          x.sp_changed |= 1u << i;
         } else {
-          SReq r = intersect1(P, a, sp[i], inc);  // incoming as AddRequirements builds it: node ∩ domains
+          SReq r = intersect1(P, a, x.sp[i], inc);  // incoming as AddRequirements builds it: node ∩ domains
           const bool empty = !(r.meta & RM_COMPL) && r.word == 0;
-          const int eop = opclass(sp[i].meta & RM_COMPL, sp[i].word != 0);
+          const int eop = opclass(x.sp[i].meta & RM_COMPL, x.sp[i].word != 0);
           if (empty && !op_neg(eop)) { *reason |= 4; return false; }  // incoming is DoesNotExist-class when empty
-          sp_changed[i] = sp_changed[i] || r.word != sp[i].word || r.meta != sp[i].meta;
-          sp[i] = r;
+          if (r.word != x.sp[i].word || r.meta != x.sp[i].meta) x.sp_changed |= 1u << i;
+          x.sp[i] = r;
         }
         if (COMMIT) {
-          S.c_bits[(size_t)P.aoff[a] * P.Cmax + c] = sp[i].word;
-          S.c_meta[(size_t)a * P.Cmax + c] = sp[i].meta;
+          S.c_bits[(size_t)sh.aoff[a] * P.Cmax + c] = x.sp[i].word;
+          S.c_meta[(size_t)a * P.Cmax + c] = x.sp[i].meta;
         }
       }
     }
   }
-  // step C: filterInstanceTypesByRequirements in type-mask space
-  int64_t newreq[KG_MAXR];
-  int thr_idx[KG_MAXR];
-  bool thr_use[KG_MAXR];
+  // step C (scalar half): requests -> fit thresholds; merged zone / capacity-type -> offering selection
+  x.thr_use = 0;
+  const int64_t* tv = sh.thr_lds ? sh.thr_val : P.thr_val;
 #pragma unroll
   for (int r = 0; r < KG_MAXR; ++r) {
-    thr_use[r] = false; thr_idx[r] = 0; newreq[r] = 0;
+    x.thr_idx[r] = 0; x.newreq[r] = 0;
     if (r < P.R) {
-      const int64_t cur = S.c_req[(size_t)r * P.Cmax + c];
       const int64_t add = sh.preq[r];
-      newreq[r] = cur + add;
-      if ((add != 0 || fresh) && newreq[r] > 0) {
-        thr_use[r] = true;
-        thr_idx[r] = thr_lookup_ge(P.thr_val + P.thr_off[r], (int)P.thr_n[r], newreq[r]);
+      if (add != 0 || fresh) {
+        x.newreq[r] = S.c_req[(size_t)r * P.Cmax + c] + add;
+        if (x.newreq[r] > 0) {
+          x.thr_use |= 1u << r;
+          x.thr_idx[r] = thr_lookup_ge(tv + (sh.thr_lds ? sh.thr_base[r] : P.a_thr_off[r]), (int)P.a_thr_n[r], x.newreq[r]);
+        }
       }
     }
   }
-  // offerings: recompute when zone / capacity-type / zone-id requirement moved (or fresh)
-  bool off_use = fresh;
-  uint64_t zmask = ~0ull, ctmask = ~0ull;
+  x.off_use = fresh;
+  x.zmask = ~0ull; x.ctmask = ~0ull;
 #pragma unroll
   for (int i = 0; i < KG_MAXSPEC; ++i) {
     if (i < P.nspec) {
-      if (i == P.slot_zone || i == P.slot_ct || i == P.slot_zid) off_use = off_use || sp_changed[i];
-      const uint64_t hm = has_mask1(P, P.spec_slot[i], sp[i]);
-      if (i == P.slot_zone) zmask &= hm;
-      if (i == P.slot_ct) ctmask = hm;
+      if (i == P.slot_zone || i == P.slot_ct || i == P.slot_zid) x.off_use = x.off_use || ((x.sp_changed >> i) & 1);
+      const uint64_t hm = has_mask1(P, sh.spec_slot[i], x.sp[i]);
+      if (i == P.slot_zone) x.zmask &= hm;
+      if (i == P.slot_ct) x.ctmask = hm;
       if (i == P.slot_zid) {
         uint64_t zm = 0;
         for (int z = 0; z < P.n_zone_vals; ++z) {
           uint8_t zid = P.zone_zid[z];
           if (zid == 0xFF || ((hm >> zid) & 1)) zm |= 1ull << z;
         }
-        zmask &= zm;
+        x.zmask &= zm;
       }
-      sp_dne_ok[i] = (sp[i].meta & RM_PRESENT) && op_neg(opclass(sp[i].meta & RM_COMPL, sp[i].word != 0));
+      if ((x.sp[i].meta & RM_PRESENT) && op_neg(opclass(x.sp[i].meta & RM_COMPL, x.sp[i].word != 0))) x.sp_dne_ok |= 1u << i;
     }
   }
-  const bool minv = P.tmpl_minv_off[tmpl + 1] > P.tmpl_minv_off[tmpl];
-  bool any = false;
-  uint32_t visited = 0;
-  for (int w = 0; w < P.TW; ++w) {
-    uint64_t m = S.c_mask[(size_t)w * P.Cmax + c];
-    visited += popc64(m);
-    // pod entries on ordinary keys
+  x.minv = P.tmpl_minv_off[tmpl + 1] > P.tmpl_minv_off[tmpl];
+  return true;
+}
+
+// filterInstanceTypesByRequirements in type-mask space: word w of the claim's remaining options after the pod.
+KG_HD uint64_t claim_word(const DevProblem& P, const SimState& S, const Shared& sh, const ClaimCtx& x, uint32_t c, int w) {
+  uint64_t m = S.c_mask[(size_t)w * P.Cmax + c];
+  const uint32_t ne = sh.vc.ne;
+  // pod entries on ordinary keys
 #pragma unroll
-    for (int j = 0; j < KG_MAXE; ++j) {
-      if ((uint32_t)j < ne) {
-        const uint32_t e = e0 + j;
-        const int a = P.e_slot[e];
-        if (P.slot2spec[a] < 0 && ent_changed[j]) {
-          uint64_t f = P.e_amask[(size_t)e * P.TW + w];
-          if (ent_dne_ok[j]) f |= P.kU[(size_t)a * P.TW + w];
-          m &= f;
-        }
-      }
-    }
-    if (fresh) {
-      // template entries on ordinary keys (merged operator class was computed if the pod shares the key)
-      for (uint32_t k = 0; k < nt; ++k) {
-        const uint32_t e = t0 + k;
-        const int a = P.e_slot[e];
-        if (P.slot2spec[a] >= 0) continue;
-        uint64_t f = P.e_amask[(size_t)e * P.TW + w];
-        bool shared = false, dne_ok = false;
-#pragma unroll
-        for (int j = 0; j < KG_MAXE; ++j)
-          if ((uint32_t)j < ne && P.e_slot[e0 + j] == a) { shared = true; dne_ok = ent_dne_ok[j]; }
-        if (!shared) {
-          const uint64_t* tb = P.rs_bits + P.e_bits[e];
-          bool anyb = false;
-          for (int i = 0; i < P.aw[a]; ++i) anyb |= tb[i] != 0;
-          dne_ok = op_neg(opclass(P.e_meta[e] & RM_COMPL, anyb));
-        }
-        if (dne_ok) f |= P.kU[(size_t)a * P.TW + w];
+  for (int j = 0; j < KG_MAXE; ++j) {
+    if ((uint32_t)j < ne && ((x.ent_changed >> j) & 1)) {
+      const PodEntry pe = sh.vc.ent[j];
+      if (pe.spec < 0) {
+        uint64_t f = P.e_amask[(size_t)pe.e * P.TW + w];
+        if ((x.ent_dne_ok >> j) & 1) f |= P.kU[(size_t)pe.slot * P.TW + w];
         m &= f;
       }
     }
-    // special keys: types whose value set meets the merged allowed set
+  }
+  if (x.fresh) {
+    // template entries on ordinary keys (merged operator class was computed if the pod shares the key)
+    for (uint32_t k = 0; k < x.nt; ++k) {
+      const uint32_t e = x.t0 + k;
+      const int a = P.e_slot[e];
+      if (sh.slot2spec[a] >= 0) continue;
+      uint64_t f = P.e_amask[(size_t)e * P.TW + w];
+      bool shared = false, dne_ok = false;
 #pragma unroll
-    for (int i = 0; i < KG_MAXSPEC; ++i) {
-      if (i < P.nspec && sp_changed[i] && (sp[i].meta & RM_PRESENT)) {
-        const int a = P.spec_slot[i];
-        uint64_t hm = has_mask1(P, a, sp[i]);
-        uint64_t f = P.kN[(size_t)a * P.TW + w];
-        if (sp_dne_ok[i]) f |= P.kU[(size_t)a * P.TW + w];
-        const int nv = P.ktwv_n[a];
-        for (uint64_t mm = hm; mm; mm &= mm - 1) {
-          int d = ctz64(mm);
-          if (d < nv) f |= P.twv[((size_t)P.ktwv_off[a] + d) * P.TW + w];
-        }
-        m &= f;
+      for (int j = 0; j < KG_MAXE; ++j)
+        if ((uint32_t)j < ne && sh.vc.ent[j].slot == a) { shared = true; dne_ok = (x.ent_dne_ok >> j) & 1; }
+      if (!shared) {
+        const uint64_t* tb = P.rs_bits + P.e_bits[e];
+        bool anyb = false;
+        for (int i = 0; i < sh.aw[a]; ++i) anyb |= tb[i] != 0;
+        dne_ok = op_neg(opclass(P.e_meta[e] & RM_COMPL, anyb));
       }
+      if (dne_ok) f |= P.kU[(size_t)a * P.TW + w];
+      m &= f;
     }
-    // fits
+  }
+  // special keys: types whose value set meets the merged allowed set
 #pragma unroll
-    for (int r = 0; r < KG_MAXR; ++r) {
-      if (thr_use[r]) {
-        if (thr_idx[r] >= (int)P.thr_n[r]) m = 0;
-        else m &= P.thr_mask[((size_t)P.thr_off[r] + thr_idx[r]) * P.TW + w];
-      }
-    }
-    if (fresh) m &= P.valid_types[w];
-    // hasOffering
-    if (off_use) {
-      uint64_t f = 0;
-      for (int z = 0; z < P.n_zone_vals; ++z) {
-        if (!((zmask >> z) & 1)) continue;
-        for (int ct = 0; ct < P.n_ct_vals; ++ct)
-          if ((ctmask >> ct) & 1) f |= P.offmask[((size_t)z * 4 + ct) * P.TW + w];
+  for (int i = 0; i < KG_MAXSPEC; ++i) {
+    if (i < P.nspec && ((x.sp_changed >> i) & 1) && (x.sp[i].meta & RM_PRESENT)) {
+      const int a = sh.spec_slot[i];
+      uint64_t hm = has_mask1(P, a, x.sp[i]);
+      uint64_t f = P.kN[(size_t)a * P.TW + w];
+      if ((x.sp_dne_ok >> i) & 1) f |= P.kU[(size_t)a * P.TW + w];
+      const int nv = P.ktwv_n[a];
+      for (uint64_t mm = hm; mm; mm &= mm - 1) {
+        int d = ctz64(mm);
+        if (d < nv) f |= P.twv[((size_t)P.ktwv_off[a] + d) * P.TW + w];
       }
       m &= f;
     }
-    any |= m != 0;
-    if (minv) S.scratch[(size_t)w * P.Cmax + c] = m;
-    else if (COMMIT) S.c_mask[(size_t)w * P.Cmax + c] = m;
   }
-  *types_visited = visited;
-  if (any && minv) {
-    // InstanceTypes.SatisfiesMinValues over the remaining set
-    for (uint32_t k = P.tmpl_minv_off[tmpl]; k < P.tmpl_minv_off[tmpl + 1]; ++k) {
-      const int a = P.minv_slot[k];
-      uint32_t distinct = 0;
-      for (int d = 0; d < P.ktwv_n[a]; ++d) {
-        bool hit = false;
-        for (int w = 0; w < P.TW; ++w) hit |= (P.twv[((size_t)P.ktwv_off[a] + d) * P.TW + w] & S.scratch[(size_t)w * P.Cmax + c]) != 0;
-        distinct += hit;
-      }
-      if (distinct < P.minv_min[k]) { any = false; *reason |= 32; }
+  // fits
+#pragma unroll
+  for (int r = 0; r < KG_MAXR; ++r) {
+    if ((x.thr_use >> r) & 1) {
+      if (x.thr_idx[r] >= (int)P.a_thr_n[r]) m = 0;
+      else m &= P.thr_mask[((size_t)P.a_thr_off[r] + x.thr_idx[r]) * P.TW + w];
     }
-    if (any && COMMIT)
-      for (int w = 0; w < P.TW; ++w) S.c_mask[(size_t)w * P.Cmax + c] = S.scratch[(size_t)w * P.Cmax + c];
   }
-  if (!any) { *reason |= 8; return false; }
-  if (COMMIT) {
-#pragma unroll
-    for (int r = 0; r < KG_MAXR; ++r) if (r < P.R) S.c_req[(size_t)r * P.Cmax + c] = newreq[r];
-    S.c_npods[c] += 1;
-    // special slots touched only through the pod entries were already written by intersect<COMMIT>;
-    // Topology.Record
-    for (uint32_t li = 0; li < v.record_cnt; ++li) {
-      const ListEntry le = P.lists[v.record_off + li];
-      const Group g = P.groups[le.g];
-      if (!(le.flags & LF_INVERSE) && g.filter_cnt) {
-        bool match = false;
-        for (uint32_t f = 0; f < g.filter_cnt && !match; ++f) match = claim_compatible_rs(P, S, c, P.filters[g.filter_off + f]);
-        if (!match) continue;
-      }
-      if (g.spec == 0xFF) { record_host(S, P, g, hslot); continue; }
-      SReq r{0, 0};
-#pragma unroll
-      for (int i = 0; i < KG_MAXSPEC; ++i) if (i == g.spec) r = sp[i];
-      if (!(r.meta & RM_PRESENT)) continue;
-      if ((le.flags & LF_INVERSE) || g.type == TG_ANTI) {
-        for (uint64_t mm = r.word; mm; mm &= mm - 1) record_small(S, le.g, ctz64(mm));
-      } else if (!(r.meta & RM_COMPL) && popc64(r.word) == 1) {
-        record_small(S, le.g, ctz64(r.word));
-      }
+  if (x.fresh) m &= P.valid_types[w];
+  // hasOffering
+  if (x.off_use) {
+    uint64_t f = 0;
+    for (int z = 0; z < P.n_zone_vals; ++z) {
+      if (!((x.zmask >> z) & 1)) continue;
+      for (int ct = 0; ct < P.n_ct_vals; ++ct)
+        if ((x.ctmask >> ct) & 1) f |= P.offmask[((size_t)z * 4 + ct) * P.TW + w];
     }
+    m &= f;
+  }
+  return m;
+}
+
+// InstanceTypes.SatisfiesMinValues over the candidate option mask in scratch[.][c]
+KG_HD bool claim_minvalues_ok(const DevProblem& P, const SimState& S, uint32_t tmpl, uint32_t c) {
+  for (uint32_t k = P.tmpl_minv_off[tmpl]; k < P.tmpl_minv_off[tmpl + 1]; ++k) {
+    const int a = P.minv_slot[k];
+    uint32_t distinct = 0;
+    for (int d = 0; d < P.ktwv_n[a]; ++d) {
+      bool hit = false;
+      for (int w = 0; w < P.TW; ++w) hit |= (P.twv[((size_t)P.ktwv_off[a] + d) * P.TW + w] & S.scratch[(size_t)w * P.Cmax + c]) != 0;
+      distinct += hit;
+    }
+    if (distinct < P.minv_min[k]) return false;
   }
   return true;
+}
+
+// Commit tail of NodeClaim.Add (after claim_prepare<true> and the option mask copy): requests, pod count, Topology.Record.
+KG_HD void claim_commit_tail(const DevProblem& P, const SimState& S, const Shared& sh, const ClaimCtx& x, uint32_t c) {
+#pragma unroll
+  for (int r = 0; r < KG_MAXR; ++r) {
+    if (r < P.R && (sh.preq[r] != 0 || x.fresh)) {
+      S.c_req[(size_t)r * P.Cmax + c] = x.newreq[r];
+      if (!x.fresh) S.c_head[(size_t)r * P.Cmax + c] -= sh.preq[r];
+    }
+  }
+  S.c_npods[c] += 1;
+  const Variant& v = sh.vc.v;
+  const uint32_t hslot = P.N + c;
+  for (uint32_t li = 0; li < v.record_cnt; ++li) {
+    const ListEntry le = P.lists[v.record_off + li];
+    const Group g = P.groups[le.g];
+    if (!(le.flags & LF_INVERSE) && g.filter_cnt) {
+      bool match = false;
+      for (uint32_t f = 0; f < g.filter_cnt && !match; ++f) match = claim_compatible_rs(P, S, c, P.filters[g.filter_off + f]);
+      if (!match) continue;
+    }
+    if (g.spec == 0xFF) { record_host(S, P, g, hslot); continue; }
+    SReq r{0, 0};
+#pragma unroll
+    for (int i = 0; i < KG_MAXSPEC; ++i) if (i == g.spec) r = x.sp[i];
+    if (!(r.meta & RM_PRESENT)) continue;
+    if ((le.flags & LF_INVERSE) || g.type == TG_ANTI) {
+      for (uint64_t mm = r.word; mm; mm &= mm - 1) record_small(S, le.g, ctz64(mm));
+    } else if (!(r.meta & RM_COMPL) && popc64(r.word) == 1) {
+      record_small(S, le.g, ctz64(r.word));
+    }
+  }
+}
+
+// max allocatable per active resource over the option mask of claim c, minus its requests: the prefilter's headroom.
+// One thread per (resource, word); combined through LDS-free global atomics is overkill: a single thread per resource
+// walks the (short) mask.  Called when a claim is created and when the prefilter let an infeasible claim through.
+KG_HD void claim_refresh_head(const DevProblem& P, const SimState& S, uint32_t c, int r) {
+  int64_t mx = 0;
+  const int64_t* al = P.alloc + (size_t)P.a_res[r] * P.T;
+  for (int w = 0; w < P.TW; ++w)
+    for (uint64_t mm = S.c_mask[(size_t)w * P.Cmax + c]; mm; mm &= mm - 1) {
+      const int64_t v = al[w * 64 + ctz64(mm)];
+      if (v > mx) mx = v;
+    }
+  S.c_head[(size_t)r * P.Cmax + c] = mx - S.c_req[(size_t)r * P.Cmax + c];
 }
 
 // ------------------------------------------------------------------ ExistingNode.Add for node n (scan position)
 template <bool COMMIT>
 KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, uint32_t n, uint32_t* reason) {
-  const Variant& v = sh.v;
+  const Variant& v = sh.vc.v;
   const uint32_t wi = n >> 6, bi = n & 63;
   if (!((P.ntol[(size_t)v.tolset * P.NW + wi] >> bi) & 1)) { *reason |= 1; return false; }
   // resources first (cheap reject), as upstream does
-  for (int k = 0; k < sh.npr; ++k) {
-    const int r = sh.pr_res[k];
-    if (S.nreq[(size_t)r * P.N + n] + sh.preq[r] > P.navail[(size_t)r * P.N + n]) { *reason |= 64; return false; }
+  for (int r = 0; r < P.R; ++r) {
+    if (sh.preq[r] != 0 && S.nreq[(size_t)r * P.N + n] + sh.preq[r] > P.navail[(size_t)r * P.N + n]) { *reason |= 64; return false; }
   }
   if (!((P.nlab[(size_t)v.rs * P.NW + wi] >> bi) & 1)) { *reason |= 2; return false; }
-  for (uint32_t li = 0; li < v.match_cnt; ++li) {
-    const ListEntry le = P.lists[v.match_off + li];
-    const Group g = P.groups[le.g];
+  for (uint32_t li = 0; li < sh.vc.nlist; ++li) {
+    const ListEntry le = sh.vc.lst[li].le;
+    const Group g = sh.vc.lst[li].g;
     const bool self = le.flags & LF_SELF;
     if (g.spec == 0xFF) {
       if (!topo_host(S, P, g, self, n)) { *reason |= 4; return false; }
@@ -696,10 +767,7 @@ KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, u
     if (!o.ok || !((o.opts >> d) & 1)) { *reason |= 4; return false; }
   }
   if (COMMIT) {
-    for (int k = 0; k < sh.npr; ++k) {
-      const int r = sh.pr_res[k];
-      S.nreq[(size_t)r * P.N + n] += sh.preq[r];
-    }
+    for (int r = 0; r < P.R; ++r) if (sh.preq[r] != 0) S.nreq[(size_t)r * P.N + n] += sh.preq[r];
     for (uint32_t li = 0; li < v.record_cnt; ++li) {
       const ListEntry le = P.lists[v.record_off + li];
       const Group g = P.groups[le.g];
@@ -719,14 +787,30 @@ KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, u
 
 // ------------------------------------------------------------------ one Solve by one workgroup
 // NT = threads in the workgroup.  `sh` lives in LDS.
-template <int NT, bool STATS>
+template <int NT>
 KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint32_t n_queue) {
+  const bool STATS = P.stats != 0;
+  const uint32_t TWP = (uint32_t)P.TWP;      // threads per evaluation group (power of two >= TW)
+  const uint32_t GP = NT / TWP;              // survivors evaluated per pass
+  // ---- stage the small problem tables in LDS
   KG_FOR_THREADS(tid, NT) {
     if (tid == 0) {
-      sh.qhead = 0; sh.qlen = n_queue; sh.epoch = 1; sh.nclaims = S.header[0]; sh.done = 0; sh.hostname_ctr = 0; sh.seq = 0;
+      sh.qhead = 0; sh.qlen = n_queue; sh.epoch = 1; sh.nclaims = S.header[0]; sh.done = 0; sh.hostname_ctr = 0; sh.seq = 0; sh.last_c = KG_NOIDX; sh.last_new = 0;
+      uint32_t tot = 0;
+      for (int r = 0; r < P.R; ++r) { sh.thr_base[r] = tot; tot += P.a_thr_n[r]; }
+      sh.thr_lds = tot <= (uint32_t)KG_THR_LDS;
     }
+    for (int a = tid; a < P.Ka; a += NT) { sh.aoff[a] = P.aoff[a]; sh.aw[a] = P.aw[a]; sh.slot2spec[a] = P.slot2spec[a]; }
+    for (int i = tid; i < P.nspec; i += NT) sh.spec_slot[i] = P.spec_slot[i];
   }
   KG_SYNC();
+  if (sh.thr_lds) {
+    KG_FOR_THREADS(tid, NT) {
+      for (int r = 0; r < P.R; ++r)
+        for (uint32_t i = tid; i < P.a_thr_n[r]; i += NT) sh.thr_val[sh.thr_base[r] + i] = P.thr_val[P.a_thr_off[r] + i];
+    }
+    KG_SYNC();
+  }
   const uint32_t QCAP = (uint32_t)P.P + 1;
   while (true) {
     // ---- Queue.Pop
@@ -741,22 +825,25 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
             sh.qhead = (sh.qhead + 1) % QCAP;
             sh.qlen -= 1;
             sh.variant = S.pod_variant[pod];
-            sh.v = P.variants[sh.variant];
             sh.best = KG_NOIDX;
-            sh.placed = 0;
             sh.reason = 0;
-            int npr = 0;
-            for (int r = 0; r < P.R; ++r) {
-              sh.preq[r] = P.preq[(size_t)r * P.P + pod];
-              if (sh.preq[r] != 0) sh.pr_res[npr++] = (uint8_t)r;
-            }
-            sh.npr = npr;
           }
         }
       }
     }
     KG_SYNC();
     if (sh.done) break;
+    // ---- pod context: one coalesced copy of the variant's precompiled record + the pod's requests
+    KG_FOR_THREADS(tid, NT) {
+      const uint64_t* src = (const uint64_t*)(P.vctx + sh.variant);
+      uint64_t* dst = (uint64_t*)&sh.vc;
+      for (uint32_t i = tid; i < sizeof(VariantCtx) / 8; i += NT) dst[i] = src[i];
+      if (tid >= NT - KG_MAXR) {
+        const int r = tid - (NT - KG_MAXR);
+        sh.preq[r] = r < P.R ? P.preq[(size_t)sh.pod * P.R + r] : 0;
+      }
+    }
+    KG_SYNC();
     // ---- existing nodes, first feasible in scan order
     for (uint32_t base = 0; base < (uint32_t)P.N; base += NT) {
       KG_FOR_THREADS(tid, NT) {
@@ -786,31 +873,131 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     if (STATS) {
       KG_FOR_THREADS(tid, NT) { if (tid == 0) S.counters[0] += P.N; }
     }
-    // ---- in-flight NodeClaims: first feasible in (pod count, stable) order = minimum claim_key
+    // ---- in-flight NodeClaims: first feasible in (pod count, stable) order = minimum claim_key.
+    // Rounds of: prefilter a range of claims into the survivor list -> order the survivors -> exact NodeClaim.Add on
+    // them, GP at a time, until one accepts the pod.  A later round only looks for keys below the best so far.
     KG_FOR_THREADS(tid, NT) {
-      if (tid == 0) { sh.bestkey = ~0ull; sh.st_vis = 0; sh.st_types = 0; }
+      // (sh.placed is reset here, two barriers after the last uniform read of it, not in Queue.Pop)
+      // The reference sorts newNodeClaims at this point of every add(); what happens after (one pod added to a claim,
+      // or one claim appended) is not re-sorted, and Results returns the slice as it stands: remember that one change.
+      if (tid == 0) { sh.bestkey = ~0ull; sh.scan_base = 0; sh.placed = 0; sh.last_c = KG_NOIDX; sh.last_new = 0; }
     }
     KG_SYNC();
-    for (uint32_t base = 0; base < sh.nclaims; base += NT) {
+    while (sh.scan_base < sh.nclaims) {
+      KG_FOR_THREADS(tid, NT) { if (tid == 0) sh.nsurv = 0; }
+      KG_SYNC();
+      // prefilter: conservative, coalesced over claims
+      const uint32_t round_base = sh.scan_base;
+      uint32_t round_end = round_base;
+      for (; round_end < sh.nclaims && round_end + NT <= round_base + (uint32_t)KG_MAXSURV; round_end += NT) {
+        KG_FOR_THREADS(tid, NT) {
+          const uint32_t c = round_end + tid;
+          if (c < sh.nclaims) {
+            bool ok = ((P.tol_tmpl[sh.vc.v.tolset] >> S.c_tmpl[c]) & 1) && sh.vc.v.host_claim_ok;
+            for (int r = 0; ok && r < P.R; ++r) ok = sh.preq[r] == 0 || S.c_head[(size_t)r * P.Cmax + c] >= sh.preq[r];
+            if (ok) {
+              uint64_t any = 0;
+              const uint64_t* pm = P.podmask + (size_t)sh.variant * P.TW;
+              for (int w = 0; w < P.TW; ++w) any |= S.c_mask[(size_t)w * P.Cmax + c] & pm[w];
+              ok = any != 0;
+            }
+            if (ok) {
+              const unsigned long long key = claim_key(S.c_npods[c], S.c_stamp[c], c);
+              if (key < sh.bestkey) {
+                const uint32_t i = atomic_inc_u32(&sh.nsurv);
+                sh.surv[i] = c;
+                sh.skey[i] = key;
+              }
+            }
+          }
+        }
+        KG_SYNC();
+      }
+      KG_FOR_THREADS(tid, NT) { if (tid == 0) sh.scan_base = round_end < sh.nclaims ? round_end : sh.nclaims; }
+      // order the survivors by key (rank by counting; keys are unique)
+      const uint32_t ns = sh.nsurv;
       KG_FOR_THREADS(tid, NT) {
-        const uint32_t c = base + tid;
-        if (c < sh.nclaims) {
-          uint32_t reason = 0, tv = 0;
-          const bool ok = eval_claim<false>(P, S, sh, c, false, &reason, &tv);
-          if (ok) atomic_min_u64(&sh.bestkey, claim_key(S.c_npods[c], S.c_stamp[c], c));
-          if (STATS) S.scratch[(size_t)(P.TW) * P.Cmax + c] = (reason & ~(8u | 32u)) ? 0 : tv;  // reached the type filter
+        for (uint32_t i = tid; i < ns; i += NT) {
+          const unsigned long long k = sh.skey[i];
+          uint32_t rank = 0;
+          for (uint32_t j = 0; j < ns; ++j) rank += sh.skey[j] < k;
+          sh.sorted[rank] = sh.surv[i];
+        }
+        if (tid == 0) { sh.pass_lo = 0; sh.winner = KG_NOIDX; }
+      }
+      KG_SYNC();
+      // exact evaluation in scan order, GP survivors per pass, TWP threads each
+      while (sh.pass_lo < ns && sh.winner == KG_NOIDX) {
+        const uint32_t lo = sh.pass_lo;
+        KG_FOR_THREADS(tid, NT) { if ((uint32_t)tid < GP) sh.sfeas[tid] = 0; }
+        KG_SYNC();
+        KG_FOR_THREADS(tid, NT) {
+          const uint32_t gi = (uint32_t)tid / TWP, w = (uint32_t)tid % TWP;
+          if (lo + gi < ns && w < (uint32_t)P.TW) {
+            const uint32_t c = sh.sorted[lo + gi];
+            ClaimCtx x;
+            uint32_t reason = 0;
+            if (claim_prepare<false>(P, S, sh, c, false, x, &reason)) {
+              const uint64_t m = claim_word(P, S, sh, x, c, (int)w);
+              S.scratch[(size_t)w * P.Cmax + c] = m;
+              if (m) sh.sfeas[gi] = 1;
+            }
+          }
+        }
+        KG_SYNC();
+        KG_FOR_THREADS(tid, NT) {
+          if (tid == 0) {
+            for (uint32_t gi = 0; gi < GP && lo + gi < ns; ++gi) {
+              const uint32_t c = sh.sorted[lo + gi];
+              bool ok = sh.sfeas[gi] != 0;
+              if (ok) {
+                const uint32_t tmpl = S.c_tmpl[c];
+                if (P.tmpl_minv_off[tmpl + 1] > P.tmpl_minv_off[tmpl]) ok = claim_minvalues_ok(P, S, tmpl, c);
+              }
+              if (ok) { sh.winner = c; break; }
+              // the prefilter let an infeasible claim through: recompute its headroom if its options changed since
+              if (S.c_hstamp[c] != S.c_stamp[c]) { sh.sfeas[gi] = 2; S.c_hstamp[c] = S.c_stamp[c]; }
+            }
+            sh.pass_lo = lo + GP;
+          }
+        }
+        KG_SYNC();
+        // tighten the headroom of false survivors whose options changed since it was last computed
+        KG_FOR_THREADS(tid, NT) {
+          const uint32_t gi = (uint32_t)tid / KG_MAXR;
+          const int r = tid % KG_MAXR;
+          if (gi < GP && lo + gi < ns && r < P.R && sh.sfeas[gi] == 2) {
+            const uint32_t c = sh.sorted[lo + gi];
+            claim_refresh_head(P, S, c, r);
+          }
+        }
+        KG_SYNC();
+      }
+      KG_FOR_THREADS(tid, NT) {
+        if (tid == 0 && sh.winner != KG_NOIDX) {
+          const uint32_t c = sh.winner;
+          sh.bestkey = claim_key(S.c_npods[c], S.c_stamp[c], c);
         }
       }
+      KG_SYNC();
     }
-    KG_SYNC();
     if (STATS) {
-      // rows the reference visits: every claim up to and including the first feasible one
+      // rows the reference visits: every claim up to and including the first feasible one; a visited claim's options
+      // count when the pod got as far as the instance-type filter
+      KG_FOR_THREADS(tid, NT) { if (tid == 0) { sh.st_vis = 0; sh.st_types = 0; } }
+      KG_SYNC();
       for (uint32_t base = 0; base < sh.nclaims; base += NT) {
         KG_FOR_THREADS(tid, NT) {
           const uint32_t c = base + tid;
           if (c < sh.nclaims && claim_key(S.c_npods[c], S.c_stamp[c], c) <= sh.bestkey) {
             atomic_add_u32(&sh.st_vis, 1u);
-            atomic_add_u64(&sh.st_types, S.scratch[(size_t)(P.TW) * P.Cmax + c]);
+            ClaimCtx x;
+            uint32_t reason = 0;
+            if (claim_prepare<false>(P, S, sh, c, false, x, &reason)) {
+              uint32_t tv = 0;
+              for (int w = 0; w < P.TW; ++w) tv += popc64(S.c_mask[(size_t)w * P.Cmax + c]);
+              atomic_add_u64(&sh.st_types, tv);
+            }
           }
         }
       }
@@ -820,11 +1007,19 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
       }
     }
     if (sh.bestkey != ~0ull) {
+      // commit: option mask words in parallel, the scalar state by one thread
       KG_FOR_THREADS(tid, NT) {
+        const uint32_t c = (uint32_t)(sh.bestkey & 0xFFFFFu);
+        if (tid >= 64 && tid < 64 + P.TW) {
+          const int w = tid - 64;
+          S.c_mask[(size_t)w * P.Cmax + c] = S.scratch[(size_t)w * P.Cmax + c];
+        }
         if (tid == 0) {
-          const uint32_t c = (uint32_t)(sh.bestkey & 0xFFFFFu);
-          uint32_t reason = 0, tv = 0;
-          eval_claim<true>(P, S, sh, c, false, &reason, &tv);
+          ClaimCtx x;
+          uint32_t reason = 0;
+          sh.last_c = c; sh.last_npods = S.c_npods[c]; sh.last_stamp = S.c_stamp[c];
+          claim_prepare<true>(P, S, sh, c, false, x, &reason);
+          claim_commit_tail(P, S, sh, x, c);
           S.c_stamp[c] = ++sh.seq;
           S.pod_kind[sh.pod] = 2;
           S.pod_index[sh.pod] = (int32_t)c;
@@ -840,7 +1035,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
       if (c >= (uint32_t)P.Cmax) break;
       // filterByRemainingResources + NewNodeClaim: materialise claim c from template t
       KG_FOR_THREADS(tid, NT) {
-        if (tid == 0) { sh.fresh_ok = 1; }
+        if (tid == 0) { sh.fresh_lim = 0; sh.fresh_any = 0; sh.fresh_ok = 0; }
       }
       KG_SYNC();
       KG_FOR_THREADS(tid, NT) {
@@ -850,16 +1045,19 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
           if (P.tmpl_has_limits[t]) {
             for (int r = 0; r < P.R; ++r) {
               if (!P.tmpl_limit_res[(size_t)r * P.NP + t]) continue;
-              const int idx = thr_lookup_le(P.cthr_val + P.cthr_off[r], (int)P.cthr_n[r], S.remaining[(size_t)r * P.NP + t]);
-              if (idx < 0) m = 0; else m &= P.cthr_mask[((size_t)P.cthr_off[r] + idx) * P.TW + w];
+              const int idx = thr_lookup_le(P.cthr_val + P.a_cthr_off[r], (int)P.a_cthr_n[r], S.remaining[(size_t)r * P.NP + t]);
+              if (idx < 0) m = 0; else m &= P.cthr_mask[((size_t)P.a_cthr_off[r] + idx) * P.TW + w];
             }
           }
           S.c_mask[(size_t)w * P.Cmax + c] = m;
+          if (m) sh.fresh_lim = 1;
         }
         for (int a = tid; a < P.Ka; a += NT) S.c_meta[(size_t)a * P.Cmax + c] = 0;
         for (int i = tid; i < P.Wa; i += NT) S.c_bits[(size_t)i * P.Cmax + c] = 0;
         for (int r = tid; r < P.R; r += NT) S.c_req[(size_t)r * P.Cmax + c] = P.tmpl_req[(size_t)r * P.NP + t];
         if (tid == 0) { S.c_npods[c] = 0; S.c_tmpl[c] = (uint16_t)t; }
+        // hostname placeholder registered for this attempt: hcount rows of slot N+c start at zero
+        for (int gh = tid; gh < P.GH; gh += NT) S.hcount[(size_t)gh * P.H + P.N + c] = 0;
       }
       KG_SYNC();
       KG_FOR_THREADS(tid, NT) {
@@ -872,40 +1070,87 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
         }
       }
       KG_SYNC();
+      if (!sh.fresh_lim) {
+        KG_FOR_THREADS(tid, NT) { if (tid == 0) sh.reason |= 16; }  // all available instance types exceed limits
+        KG_SYNC();
+        continue;
+      }
+      // NodeClaim.Add on the fresh claim: one thread per option-mask word
+      KG_FOR_THREADS(tid, NT) {
+        if (tid < P.TW) {
+          ClaimCtx x;
+          uint32_t reason = 0;
+          if (claim_prepare<false>(P, S, sh, c, true, x, &reason)) {
+            const uint64_t m = claim_word(P, S, sh, x, c, tid);
+            S.scratch[(size_t)tid * P.Cmax + c] = m;
+            if (m) sh.fresh_any = 1;
+            if (tid == 0) sh.fresh_ok = 1;
+          } else if (tid == 0) {
+            sh.reason |= reason;
+          }
+        }
+      }
+      KG_SYNC();
       KG_FOR_THREADS(tid, NT) {
         if (tid == 0) {
-          bool anym = false;
-          for (int w = 0; w < P.TW; ++w) anym |= S.c_mask[(size_t)w * P.Cmax + c] != 0;
-          if (!anym) { sh.reason |= 16; }  // all available instance types exceed limits
-          else {
-            // hostname placeholder registered for this attempt: hcount rows of slot N+c start at zero
-            for (int gh = 0; gh < P.GH; ++gh) S.hcount[(size_t)gh * P.H + P.N + c] = 0;
-            uint32_t reason = 0, tv = 0;
-            if (STATS) { S.counters[3] += 1; }
-            const bool ok = eval_claim<true>(P, S, sh, c, true, &reason, &tv);
-            if (STATS) { if (!(reason & ~(8u | 32u))) S.counters[2] += tv; }
-            sh.reason |= reason;
-            if (ok) {
-              // subtractMax: charge the worst-case capacity of the remaining options against the limits
-              if (P.tmpl_has_limits[t]) {
-                for (int r = 0; r < P.R; ++r) {
-                  if (!P.tmpl_limit_res[(size_t)r * P.NP + t]) continue;
-                  int64_t mx = 0;
-                  for (int w = 0; w < P.TW; ++w)
-                    for (uint64_t mm = S.c_mask[(size_t)w * P.Cmax + c]; mm; mm &= mm - 1) {
-                      const int64_t cv = P.cap[(size_t)r * P.T + (w * 64 + ctz64(mm))];
-                      if (cv > mx) mx = cv;
-                    }
-                  S.remaining[(size_t)r * P.NP + t] -= mx;
-                }
-              }
-              S.c_stamp[c] = ++sh.seq;
-              sh.nclaims += 1;
-              S.pod_kind[sh.pod] = 2;
-              S.pod_index[sh.pod] = (int32_t)c;
-              sh.placed = 1;
+          if (STATS) {
+            S.counters[3] += 1;
+            if (sh.fresh_ok) {
+              uint32_t tv = 0;
+              for (int w = 0; w < P.TW; ++w) tv += popc64(S.c_mask[(size_t)w * P.Cmax + c]);
+              S.counters[2] += tv;
             }
           }
+          bool ok = sh.fresh_ok && sh.fresh_any;
+          if (sh.fresh_ok && !sh.fresh_any) sh.reason |= 8;
+          if (ok && P.tmpl_minv_off[t + 1] > P.tmpl_minv_off[t] && !claim_minvalues_ok(P, S, (uint32_t)t, c)) { ok = false; sh.reason |= 32 | 8; }
+          sh.fresh_ok = ok;
+        }
+      }
+      KG_SYNC();
+      {
+        // every wave reads the verdict before the next attempt's reset may overwrite it
+        const bool ok = sh.fresh_ok != 0;
+        KG_SYNC();
+        if (!ok) continue;
+      }
+      KG_FOR_THREADS(tid, NT) {
+        if (tid >= 64 && tid < 64 + P.TW) {
+          const int w = tid - 64;
+          S.c_mask[(size_t)w * P.Cmax + c] = S.scratch[(size_t)w * P.Cmax + c];
+        }
+        if (tid == 0) {
+          ClaimCtx x;
+          uint32_t reason = 0;
+          claim_prepare<true>(P, S, sh, c, true, x, &reason);
+          claim_commit_tail(P, S, sh, x, c);
+        }
+      }
+      KG_SYNC();
+      KG_FOR_THREADS(tid, NT) {
+        // headroom of the new claim; subtractMax: charge the worst-case capacity of the remaining options against the limits
+        if (tid < P.R) claim_refresh_head(P, S, c, tid);
+        if (tid >= 64 && tid < 64 + P.R && P.tmpl_has_limits[t]) {
+          const int r = tid - 64;
+          if (P.tmpl_limit_res[(size_t)r * P.NP + t]) {
+            int64_t mx = 0;
+            const int64_t* cp = P.cap + (size_t)P.a_res[r] * P.T;
+            for (int w = 0; w < P.TW; ++w)
+              for (uint64_t mm = S.c_mask[(size_t)w * P.Cmax + c]; mm; mm &= mm - 1) {
+                const int64_t cv = cp[w * 64 + ctz64(mm)];
+                if (cv > mx) mx = cv;
+              }
+            S.remaining[(size_t)r * P.NP + t] -= mx;
+          }
+        }
+        if (tid == 0) {
+          S.c_stamp[c] = ++sh.seq;
+          S.c_hstamp[c] = sh.seq;
+          sh.last_c = c; sh.last_new = 1;
+          sh.nclaims += 1;
+          S.pod_kind[sh.pod] = 2;
+          S.pod_index[sh.pod] = (int32_t)c;
+          sh.placed = 1;
         }
       }
       KG_SYNC();
@@ -920,8 +1165,8 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
         S.pod_reason[pod] = sh.reason ? sh.reason : 8;
         S.queue[(sh.qhead + sh.qlen) % QCAP] = pod;
         sh.qlen += 1;
-        if (sh.v.next >= 0) {
-          S.pod_variant[pod] = (uint32_t)sh.v.next;
+        if (sh.vc.v.next >= 0) {
+          S.pod_variant[pod] = (uint32_t)sh.vc.v.next;
           sh.epoch += 1;  // lastLen = {} on a relaxed push
           S.header[1] += 1;
         } else {
@@ -933,7 +1178,10 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     KG_SYNC();
   }
   KG_FOR_THREADS(tid, NT) {
-    if (tid == 0) S.header[0] = sh.nclaims;
+    if (tid == 0) {
+      S.header[0] = sh.nclaims;
+      S.header[2] = sh.last_c; S.header[3] = sh.last_npods; S.header[4] = sh.last_stamp; S.header[5] = sh.last_new;
+    }
   }
   KG_SYNC();
 }
@@ -955,6 +1203,7 @@ struct PrepassTables {
   const uint32_t* rs_host_nodes; // node scan positions named by the hostname requirement
   uint64_t* e_amask_out;       // [E][TW]
   uint64_t* nlab_out;          // [S][NW]
+  uint64_t* podmask_out;       // [NV][TW]
 };
 
 KG_HD bool entry_has(const DevProblem& P, uint32_t e, int a, uint32_t v) {
@@ -980,6 +1229,41 @@ KG_HD uint64_t type_filter_word(const DevProblem& P, uint32_t e, int w) {
   for (uint32_t v = 0; v < nv; ++v)
     if (entry_has(P, e, a, v)) acc |= P.twv[((size_t)row0 + v) * P.TW + w];
   return acc;
+}
+
+// word w of "types pod variant vi can ever accept": for every requirement entry of the pod, the types whose value
+// satisfies it, that do not mention the key, or that list it as DoesNotExist (admissible when the merged operator is
+// NotIn / DoesNotExist); and an available offering in a zone / capacity type the pod itself allows.  A NodeClaim's
+// options after NodeClaim.Add are always a subset of (its options AND this mask): the prefilter's soundness.
+KG_HD uint64_t pod_mask_word(const DevProblem& P, uint32_t vi, int w) {
+  const VariantCtx& vc = P.vctx[vi];
+  uint64_t m = ~0ull;
+  uint64_t zmask = ~0ull, ctmask = ~0ull;
+  for (uint32_t j = 0; j < vc.ne; ++j) {
+    const PodEntry& pe = vc.ent[j];
+    m &= type_filter_word(P, pe.e, w) | P.kU[(size_t)pe.slot * P.TW + w];
+    if (pe.spec >= 0 && (pe.spec == P.slot_zone || pe.spec == P.slot_ct || pe.spec == P.slot_zid)) {
+      SReq r{pe.meta, (P.rs_bits + P.e_bits[pe.e])[0]};
+      const uint64_t hm = has_mask1(P, pe.slot, r);
+      if (pe.spec == P.slot_zone) zmask &= hm;
+      if (pe.spec == P.slot_ct) ctmask &= hm;
+      if (pe.spec == P.slot_zid) {
+        uint64_t zm = 0;
+        for (int z = 0; z < P.n_zone_vals; ++z) {
+          uint8_t zid = P.zone_zid[z];
+          if (zid == 0xFF || ((hm >> zid) & 1)) zm |= 1ull << z;
+        }
+        zmask &= zm;
+      }
+    }
+  }
+  uint64_t f = 0;
+  for (int z = 0; z < P.n_zone_vals; ++z) {
+    if (!((zmask >> z) & 1)) continue;
+    for (int ct = 0; ct < P.n_ct_vals; ++ct)
+      if ((ctmask >> ct) & 1) f |= P.offmask[((size_t)z * 4 + ct) * P.TW + w];
+  }
+  return m & f;
 }
 
 // Requirements.Compatible(node labels + hostname, requirement set s) with no undefined-label allowance

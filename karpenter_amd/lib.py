@@ -39,6 +39,7 @@ class Library:
         d.kg_cluster_free.argtypes = [C.c_void_p]
         d.kg_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         d.kg_backend.restype = C.c_char_p
+        d.kg_set_collect_stats.argtypes = [C.c_void_p, C.c_int32]
         self.ctx = C.c_void_p()
         st = d.kg_init(device, C.byref(self.ctx))
         if st != 0:
@@ -46,6 +47,10 @@ class Library:
 
     def backend(self):
         return self.dll.kg_backend().decode()
+
+    def set_collect_stats(self, enabled):
+        """Reference-visit counters (kg_results.visited_*, algorithmic_bytes): exact but one extra pass per placement."""
+        self._check(self.dll.kg_set_collect_stats(self.ctx, 1 if enabled else 0))
 
     def _check(self, st):
         if st != 0:

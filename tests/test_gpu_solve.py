@@ -37,6 +37,28 @@ def test_c2_mixed(L, n, seed):
     check(L, Problem(types, wl.mixed_pods(n, seed, zones, families(types)), [wl.default_nodepool()]))
 
 
+def test_small_batches_sweep(L):
+    zones, types = catalog776()
+    fams = families(types)
+    for seed in (1, 2):
+        for n in (1, 2, 3, 4, 5, 6, 7, 9, 13, 21, 34, 55):
+            check(L, Problem(types, wl.mixed_pods(n, seed, zones, fams), [wl.default_nodepool()]))
+
+
+def test_stats_off_same_result(L):
+    """The visit counters are optional: placements must not depend on them."""
+    zones, types = catalog776()
+    prob = Problem(types, wl.mixed_pods(700, 5, zones, families(types)), [wl.default_nodepool()])
+    ro = prob.run_oracle()
+    L.set_collect_stats(False)
+    try:
+        rg = prob.run_library(L)
+    finally:
+        L.set_collect_stats(True)
+    d = diff_results(ro.decode(), rg.decode())
+    assert d == "", d
+
+
 def test_c2_full(L):
     zones, types = catalog776()
     ro, rg = check(L, Problem(types, wl.mixed_pods(10000, 42, zones, families(types)), [wl.default_nodepool()]))

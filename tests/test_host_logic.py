@@ -38,3 +38,13 @@ def test_c1_homogeneous(L):
 def test_c2_mixed(L, n, seed):
     zones, types = catalog776()
     check(L, Problem(types, wl.mixed_pods(n, seed, zones, families(types)), [wl.default_nodepool()]))
+
+
+def test_small_batches_sweep(L):
+    """Every batch size 1..24 (x3 seeds): covers 'the last add() appended / touched a claim after the last sort'
+    (Results.NewNodeClaims order), single-pod and two-claim corner cases."""
+    zones, types = catalog776()
+    fams = families(types)
+    for seed in (1, 2, 3):
+        for n in range(1, 25):
+            check(L, Problem(types, wl.mixed_pods(n, seed, zones, fams), [wl.default_nodepool()]))
