@@ -11,6 +11,8 @@ struct kg_ctx {
   kg::StrMap lab;  // pod-label / namespace / uid strings (selector space, never on the device)
   std::string last_error;
   kg_stats stats{};
+  bool collect_timers = false;
+  int block_threads = 256;  // workgroup size of k_solve (256 or 1024)
   bool collect_stats = true;  // maintain the reference-visit counters (exact; costs an extra pass per placement)
   std::mutex mu;
   uint32_t kHostname, kZone, kCT, kZid, kNodePool, kInstanceType;

@@ -5,6 +5,7 @@
 #include <string>
 
 #include "hal.hpp"
+#include "globalize.hpp"
 
 namespace kg {
 
@@ -38,10 +39,15 @@ __global__ void __launch_bounds__(256) k_pod_mask(DevProblem P, PrepassTables X)
 
 // k_solve: one workgroup = one Scheduler.Solve (persistent over the whole pod queue)
 template <int NT>
-__global__ void __launch_bounds__(NT) k_solve(DevProblem P, const SimState* sims, const uint32_t* nqueue) {
+__global__ void __launch_bounds__(NT) k_solve(DevProblem Pin, const SimState* sims, const uint32_t* nqueue) {
   __shared__ Shared sh;
-  const SimState S = sims[blockIdx.x];
+  DevProblem P = Pin;
+  SimState S = sims[blockIdx.x];
+  globalize(P);
+  globalize(S);
+  const unsigned long long c0 = clock64(), w0 = wall_clock64();
   solve_block<NT>(P, S, sh, nqueue[blockIdx.x]);
+  if ((P.stats & 2) && threadIdx.x == 0) { S.counters[24] = clock64() - c0; S.counters[25] = wall_clock64() - w0; }
 }
 
 namespace hal {

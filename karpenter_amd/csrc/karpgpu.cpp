@@ -574,6 +574,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     }
   }
   C.Wa = std::max(Wa, 1);
+  if (C.Wa > KG_ROWW) throw Unsupported("requirement rows wider than 64 words (label vocabulary too large)");
   const int nspec = (int)C.spec_slot.size();
   auto spec_of_key = [&](uint32_t key) { int a = find_slot(C, key); return a < 0 ? -1 : (int)C.slot2spec[a]; };
 
@@ -1002,7 +1003,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   int TWP = 16;
   while (TWP < TW) TWP *= 2;
   if (TWP > 256) throw Unsupported("more than 16384 instance types");
-  D.TWP = TWP; D.NV = NV; D.stats = stats ? 1 : 0;
+  D.TWP = TWP; D.NV = NV; D.stats = (stats ? 1 : 0) | (ctx->collect_timers ? 2 : 0);
   for (int r = 0; r < R; ++r) {
     const uint32_t g = C.act_res[r];
     const uint32_t* toff = (const uint32_t*)(CT.image.bytes.data() + CT.o_thr_off);
@@ -1041,7 +1042,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   Arena SA;
   std::vector<int64_t> remaining0(tmpl_limits0);
   std::vector<uint32_t> header(16, 0), nqueue{(uint32_t)P};
-  std::vector<uint64_t> counters(8, 0);
+  std::vector<uint64_t> counters(32, 0);
   C.o_nreq = SA.add(nreq0);
   C.o_creq = SA.reserve((size_t)std::max(R, 1) * Cmax * 8);
   C.o_chead = SA.reserve((size_t)std::max(R, 1) * Cmax * 8);
@@ -1194,7 +1195,9 @@ const char* kg_backend(void) { return hal::backend(); }
 int32_t kg_set_collect_stats(kg_ctx* ctx, int32_t enabled) {
   if (!ctx) return KG_EINVAL;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  ctx->collect_stats = enabled != 0;
+  ctx->collect_stats = (enabled & 1) != 0;
+  ctx->collect_timers = (enabled & 2) != 0;
+  if (enabled & 4) ctx->block_threads = 1024; else ctx->block_threads = 256;  // debugging aid: per-phase ticks of k_solve printed to stderr
   return KG_OK;
 }
 
@@ -1319,20 +1322,27 @@ int32_t kg_solve(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, 
   auto t1 = std::chrono::steady_clock::now();
   float ms_pre = 0, ms_solve = 0;
   hal::launch_prepass(C->dp, C->pre, &ms_pre);
-  hal::launch_solve(C->dp, (const SimState*)C->sims_dev.ptr, 1, (const uint32_t*)((uint8_t*)C->state_dev.ptr + C->o_nqueue), 1024, &ms_solve);
+  hal::launch_solve(C->dp, (const SimState*)C->sims_dev.ptr, 1, (const uint32_t*)((uint8_t*)C->state_dev.ptr + C->o_nqueue), ctx->block_threads, &ms_solve);
   ctx->stats.kernel_launches += 3;
   // ---- results
   const int P = C->P, Cmax = C->Cmax, TW = C->TW, R = C->R, Ka = C->Ka;
   std::vector<uint8_t> pod_kind(std::max(P, 1));
   std::vector<int32_t> pod_index(std::max(P, 1));
   std::vector<uint32_t> pod_reason(std::max(P, 1)), header(16);
-  std::vector<uint64_t> counters(8);
+  std::vector<uint64_t> counters(32);
   auto sp = [&](size_t off) { return (uint8_t*)C->state_dev.ptr + off; };
   hal::d2h(pod_kind.data(), sp(C->o_podkind), P);
   hal::d2h(pod_index.data(), sp(C->o_podindex), (size_t)P * 4);
   hal::d2h(pod_reason.data(), sp(C->o_podreason), (size_t)P * 4);
   hal::d2h(header.data(), sp(C->o_header), 64);
-  hal::d2h(counters.data(), sp(C->o_counters), 64);
+  hal::d2h(counters.data(), sp(C->o_counters), 256);
+  if (ctx->collect_timers) {
+    static const char* names[] = {"pop+ctx", "nodes", "prefilter", "sort", "eval", "stats", "commit", "newclaim/relax"};
+    for (int i = 0; i < 8; ++i) fprintf(stderr, "[kg timers] %-15s %10.3f ms\n", names[i], counters[8 + i] / 1e5);
+    fprintf(stderr, "[kg timers] shader clock %.0f MHz over the launch\n", counters[25] ? counters[24] / (counters[25] / 100.0) : 0.0);
+    fprintf(stderr, "[kg timers] survivors %llu rounds %llu false_pos %llu passes %llu\n", (unsigned long long)counters[20],
+            (unsigned long long)counters[21], (unsigned long long)counters[22], (unsigned long long)counters[23]);
+  }
   const uint32_t nclaims = header[0];
   std::vector<uint32_t> order(nclaims), c_npods(nclaims), c_meta((size_t)Ka * nclaims);
   std::vector<uint16_t> c_tmpl(nclaims);

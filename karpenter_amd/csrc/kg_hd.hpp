@@ -21,7 +21,9 @@ inline void atomic_min_u32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
 inline void atomic_min_u64(unsigned long long* p, unsigned long long v) { if (v < *p) *p = v; }
 inline void atomic_add_u32(uint32_t* p, uint32_t v) { *p += v; }
 inline uint32_t atomic_inc_u32(uint32_t* p) { return (*p)++; }
+inline void atomic_or_u32(uint32_t* p, uint32_t v) { *p |= v; }
 inline void atomic_add_u64(unsigned long long* p, unsigned long long v) { *p += v; }
+inline unsigned long long now_ticks() { return 0; }
 inline int popc64(uint64_t x) { return __builtin_popcountll(x); }
 inline int ctz64(uint64_t x) { return __builtin_ctzll(x); }
 }  // namespace kg
@@ -37,7 +39,9 @@ __device__ __forceinline__ void atomic_min_u32(uint32_t* p, uint32_t v) { atomic
 __device__ __forceinline__ void atomic_min_u64(unsigned long long* p, unsigned long long v) { atomicMin(p, v); }
 __device__ __forceinline__ void atomic_add_u32(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
 __device__ __forceinline__ uint32_t atomic_inc_u32(uint32_t* p) { return atomicAdd(p, 1u); }
+__device__ __forceinline__ void atomic_or_u32(uint32_t* p, uint32_t v) { atomicOr(p, v); }
 __device__ __forceinline__ void atomic_add_u64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
+__device__ __forceinline__ unsigned long long now_ticks() { return wall_clock64(); }  // 100 MHz
 __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
 __device__ __forceinline__ int ctz64(uint64_t x) { return __ffsll((unsigned long long)x) - 1; }
 }  // namespace kg

@@ -20,8 +20,9 @@
 //   * One placement = (1) pop + one coalesced load of the pod's precompiled VariantCtx into LDS,
 //     (2) a streaming prefilter over all in-flight NodeClaims (thread per claim; conservative:
 //     toleration bit, per-resource headroom, option mask AND the pod's own type mask),
-//     (3) the exact NodeClaim.Add on the survivors in scan order, 16 threads per survivor (one per
-//     64-type word), (4) commit of the winner.
+//     (3) the exact NodeClaim.Add on the survivors in scan order, 16 at a time: each claim's requirement row is
+//     copied to LDS, the pod's requirement entries and resources are merged into it by one thread each, the
+//     instance-type filter runs one thread per 64-type word, (4) the winner's merged row is written back.
 #pragma once
 #include "kg_hd.hpp"
 
@@ -35,6 +36,9 @@ constexpr int KG_MAXLIST = 8;   // topology groups consulted for one pod
 constexpr int KG_EBITS = 32;    // requirement-value words of one pod staged in LDS
 constexpr int KG_THR_LDS = 1024;  // fit-threshold values staged in LDS
 constexpr int KG_MAXSURV = 1024;  // prefilter survivors handled per round
+constexpr int KG_MAXGP = 16;      // NodeClaims evaluated exactly per pass
+constexpr int KG_ROWW = 64;       // requirement-value words of one claim row
+constexpr int KG_TWLDS = 32;      // option-mask words of the pod's type mask staged in LDS
 constexpr uint32_t KG_NOIDX = 0xFFFFFFFFu;
 
 // requirement meta word
@@ -200,16 +204,30 @@ struct SimState {
   uint32_t* pod_reason; // [P]
   uint64_t* scratch;  // [TW+1][Cmax] candidate option masks of the survivors; row TW: per-claim visit statistic
   uint32_t* header;   // [16]: 0 nclaims, 1 relaxations, 2-5 the claim touched after the last sort (id, old pods, old stamp, new)
-  uint64_t* counters; // [8]: visited_existing, visited_claims, visited_claim_types, new_claim_scans
+  uint64_t* counters; // [32]: 8.. phase timers and scan statistics when stats&2; [0..3]: visited_existing, visited_claims, visited_claim_types, new_claim_scans
+};
+
+// One evaluation group's working copy of a NodeClaim (LDS): the claim's requirement row is loaded here, the pod is
+// merged into it in place (NodeClaim.Add steps 3-5), and the winner's copy is what the commit writes back.
+struct Row {
+  uint32_t c, tmpl, ok, reason, feas, tv;
+  uint32_t ent_changed, ent_dne_ok, sp_changed, thr_use, has_topo, pad_;
+  int32_t thr_idx[KG_MAXR];
+  int64_t req[KG_MAXR];            // claim requests; after the merge: requests including the pod
+  uint64_t topo[KG_MAXSPEC];       // Topology.AddRequirements result per special key
+  uint32_t meta[KG_MAXKA];         // requirement meta per active key
+  uint64_t bits[KG_ROWW];          // requirement value bits, Wa words
 };
 
 struct Shared {
-  uint32_t pod, variant, best, nclaims, qhead, qlen, epoch, done, placed, hostname_ctr, seq, st_vis, reason;
+  uint32_t pod, variant, best, nclaims, qhead, qlen, epoch, done, placed, seq, reason;
   uint32_t last_c, last_npods, last_stamp, last_new;  // the one claim touched since the reference's last sort.Slice
-  uint32_t nsurv, scan_base, pass_lo, winner, thr_lds, fresh_lim, fresh_any, fresh_ok;
+  uint32_t nsurv, scan_base, pass_lo, winner, win_g, thr_lds, fresh_lim, need_refresh;
+  uint32_t stage, tnext, result, st_vis;
   unsigned long long bestkey, st_types;
   int64_t preq[KG_MAXR];
   VariantCtx vc;
+  uint64_t podmask[KG_TWLDS];       // the pod variant's own type mask (prefilter)
   // small problem tables
   uint16_t aoff[KG_MAXKA], aw[KG_MAXKA];
   int8_t slot2spec[KG_MAXKA];
@@ -220,7 +238,8 @@ struct Shared {
   uint32_t surv[KG_MAXSURV];             // claim ids, in arrival order
   unsigned long long skey[KG_MAXSURV];   // their scan-order keys
   uint32_t sorted[KG_MAXSURV];           // claim ids in scan order
-  uint32_t sfeas[KG_MAXSURV / 16 + 1];   // per evaluation group of the current pass: some option remains
+  Row rows[KG_MAXGP];                    // evaluation groups of the current pass
+  Row wrow;                              // the best NodeClaim so far when the scan needs more than one round
 };
 
 // ------------------------------------------------------------------ requirement algebra
@@ -260,57 +279,6 @@ KG_HD SReq intersect1(const DevProblem& P, int a, SReq x, SReq y) {
   r.meta = c ? rm_make(true, gt, lt) : rm_make(false, 0, 0);
   r.word = w;
   return r;
-}
-
-// Generic (multi-word) intersection summary of claim slot `a` (w words at row offset off) of claim c with
-// a requirement (pm, pb).  Returns merged meta; *any = merged has any value bit; optionally writes merged bits.
-template <bool WRITE>
-KG_HD uint32_t intersect_claim_bits(const DevProblem& P, const SimState& S, int a, int w, int off, uint32_t c, uint32_t cm, uint32_t pm,
-                                    const uint64_t* pb, bool* any, bool* changed, bool* cany) {
-  bool xc = cm & RM_COMPL, yc = pm & RM_COMPL;
-  uint32_t gt = rm_gt(cm) > rm_gt(pm) ? rm_gt(cm) : rm_gt(pm);
-  uint32_t lt = min_nz(rm_lt(cm), rm_lt(pm));
-  bool dne = gt && lt && P.gtval[P.bnd_off[a] + gt - 1] >= P.ltval[P.bnd_off[a] + lt - 1];
-  bool c2 = xc && yc && !dne;
-  uint32_t meta = c2 ? rm_make(true, gt, lt) : rm_make(false, 0, 0);
-  bool anyb = false, chg = meta != cm, canyb = false;
-  for (int i = 0; i < w; ++i) {
-    uint64_t x = S.c_bits[(size_t)(off + i) * P.Cmax + c], y = pb[i];
-    canyb |= x != 0;
-    uint64_t r = dne ? 0 : ((xc && yc) ? (x | y) : (xc ? (y & ~x) : (yc ? (x & ~y) : (x & y))));
-    if (!dne && gt) r &= P.gtmask[P.bndmask_off[a] + (size_t)(gt - 1) * w + i];
-    if (!dne && lt) r &= P.ltmask[P.bndmask_off[a] + (size_t)(lt - 1) * w + i];
-    anyb |= r != 0;
-    chg |= r != x;
-    if (WRITE) S.c_bits[(size_t)(off + i) * P.Cmax + c] = r;
-  }
-  if (WRITE) S.c_meta[(size_t)a * P.Cmax + c] = meta;
-  *any = anyb;
-  *changed = chg;
-  *cany = canyb;
-  return meta;
-}
-
-// Requirements.Compatible(claim c, requirement set rs, AllowUndefinedWellKnownLabels) without merging.
-KG_HD bool claim_compatible_rs(const DevProblem& P, const SimState& S, uint32_t c, uint32_t rs) {
-  for (uint32_t e = P.rs_off[rs]; e < P.rs_off[rs + 1]; ++e) {
-    int a = P.e_slot[e];
-    uint32_t pm = P.e_meta[e];
-    const uint64_t* pb = P.rs_bits + P.e_bits[e];
-    bool panyb = false;
-    for (int i = 0; i < P.aw[a]; ++i) panyb |= pb[i] != 0;
-    int pop = opclass(pm & RM_COMPL, panyb);
-    uint32_t cm = S.c_meta[(size_t)a * P.Cmax + c];
-    if (!(cm & RM_PRESENT)) {
-      if (!((P.well_known_slots >> a) & 1) && !op_neg(pop)) return false;
-      continue;
-    }
-    bool anyb, chg, canyb;
-    uint32_t mm = intersect_claim_bits<false>(P, S, a, P.aw[a], P.aoff[a], c, cm, pm, pb, &anyb, &chg, &canyb);
-    bool empty = !(mm & RM_COMPL) && !anyb;
-    if (empty && !(op_neg(pop) && op_neg(opclass(cm & RM_COMPL, canyb)))) return false;
-  }
-  return true;
 }
 
 KG_HD int thr_lookup_ge(const int64_t* vals, int n, int64_t x) {  // first index with vals[i] >= x, n if none
@@ -425,212 +393,152 @@ KG_HD unsigned long long claim_key(uint32_t npods, uint32_t stamp, uint32_t c) {
   return ((unsigned long long)npods << 40) | ((unsigned long long)(sk & 0xFFFFFu) << 20) | c;
 }
 
-// ------------------------------------------------------------------ NodeClaim.Add, split for (claim, word) threads
-// Result of the scalar steps of NodeClaim.Add for (pod, claim): requirement merge, topology, requests.
-struct ClaimCtx {
-  uint32_t tmpl, t0, nt;
-  SReq sp[KG_MAXSPEC];
-  uint32_t sp_changed, sp_dne_ok, ent_dne_ok, ent_changed;  // bit per special slot / per pod entry
-  int64_t newreq[KG_MAXR];
-  int32_t thr_idx[KG_MAXR];
-  uint32_t thr_use;  // bit per active resource
-  uint64_t zmask, ctmask;
-  bool off_use, minv, fresh;
-};
-
+// ------------------------------------------------------------------ NodeClaim.Add on a claim row held in LDS
 KG_HD const uint64_t* entry_bits(const DevProblem& P, const Shared& sh, const PodEntry& pe) {
   return pe.bits != 0xFFFF ? sh.vc.ebits + pe.bits : P.rs_bits + P.e_bits[pe.e];
 }
 
-// Steps 1-5 of NodeClaim.Add (taints, Compatible + Add of the pod requirements, topology, requests).
-// fresh: the claim was just materialised from its template (all template keys still to be applied).
-// Returns true when the pod reaches the instance-type filter; with COMMIT also updates the claim's requirements.
-template <bool COMMIT>
-KG_HD bool claim_prepare(const DevProblem& P, const SimState& S, const Shared& sh, uint32_t c, bool fresh, ClaimCtx& x, uint32_t* reason) {
-  const Variant& v = sh.vc.v;
-  const uint32_t tmpl = S.c_tmpl[c];
-  x.tmpl = tmpl;
-  x.fresh = fresh;
-  if (!((P.tol_tmpl[v.tolset] >> tmpl) & 1)) { *reason |= 1; return false; }
-  if (!v.host_claim_ok) { *reason |= 2; return false; }
-  const uint32_t ne = sh.vc.ne;
-  x.t0 = 0; x.nt = 0;
-  if (fresh) { x.t0 = P.rs_off[P.tmpl_rs[tmpl]]; x.nt = P.rs_off[P.tmpl_rs[tmpl] + 1] - x.t0; }
-  x.sp_changed = 0; x.sp_dne_ok = 0; x.ent_dne_ok = 0; x.ent_changed = 0;
-
-  // merged view of the special (1-word) slots: start from the claim's own state
-#pragma unroll
-  for (int i = 0; i < KG_MAXSPEC; ++i) {
-    x.sp[i].meta = 0; x.sp[i].word = 0;
-    if (i < P.nspec) {
-      const int a = sh.spec_slot[i];
-      x.sp[i].meta = S.c_meta[(size_t)a * P.Cmax + c];
-      x.sp[i].word = (x.sp[i].meta & RM_PRESENT) ? S.c_bits[(size_t)sh.aoff[a] * P.Cmax + c] : 0;
-      if (fresh && (x.sp[i].meta & RM_PRESENT)) x.sp_changed |= 1u << i;
-    }
-  }
-  // step A: Requirements.Compatible(podReqs) + Add, entry by entry
-#pragma unroll
-  for (int j = 0; j < KG_MAXE; ++j) {
-    if ((uint32_t)j < ne) {
-      const PodEntry pe = sh.vc.ent[j];
-      const int a = pe.slot;
-      const uint32_t pm = pe.meta;
-      const uint64_t* pb = entry_bits(P, sh, pe);
-      const int w = pe.w;
-      const int pop = pe.opc;
-      const uint32_t cm = S.c_meta[(size_t)a * P.Cmax + c];
-      const int spi = pe.spec;
-      if (!(cm & RM_PRESENT)) {
-        if (!((P.well_known_slots >> a) & 1) && !op_neg(pop)) { *reason |= 2; return false; }
-        if (op_neg(pop)) x.ent_dne_ok |= 1u << j;
-        x.ent_changed |= 1u << j;
-        if (spi >= 0) {
-#pragma unroll
-          for (int i = 0; i < KG_MAXSPEC; ++i) if (i == spi) { x.sp[i].meta = pm; x.sp[i].word = pb[0]; x.sp_changed |= 1u << i; }
-        }
-        if (COMMIT) {
-          for (int i = 0; i < w; ++i) S.c_bits[(size_t)(pe.aoff + i) * P.Cmax + c] = pb[i];
-          S.c_meta[(size_t)a * P.Cmax + c] = pm;
-        }
-      } else {
-        bool anyb, chg, canyb;
-        const uint32_t mm = intersect_claim_bits<COMMIT>(P, S, a, w, pe.aoff, c, cm, pm, pb, &anyb, &chg, &canyb);
-        const int cop = opclass(cm & RM_COMPL, canyb);
-        const bool empty = !(mm & RM_COMPL) && !anyb;
-        if (empty && !(op_neg(pop) && op_neg(cop))) { *reason |= 2; return false; }
-        if (op_neg(opclass(mm & RM_COMPL, anyb))) x.ent_dne_ok |= 1u << j;
-        if (chg || fresh) x.ent_changed |= 1u << j;
-        if (spi >= 0) {
-#pragma unroll
-          for (int i = 0; i < KG_MAXSPEC; ++i)
-            if (i == spi) {
-              SReq xx{cm, x.sp[i].word}, y{pm, pb[0]};
-              SReq r = intersect1(P, a, xx, y);
-              if (r.word != x.sp[i].word || r.meta != x.sp[i].meta) x.sp_changed |= 1u << i;
-              x.sp[i] = r;
-            }
-        }
-      }
-    }
-  }
-  // step B: Topology.AddRequirements -> Compatible -> Add
-  const uint32_t hslot = P.N + c;
-  if (sh.vc.nlist) {
-    uint64_t topo[KG_MAXSPEC];
-    uint32_t has_topo = 0;
-#pragma unroll
-    for (int i = 0; i < KG_MAXSPEC; ++i) topo[i] = ~0ull;
-    for (uint32_t li = 0; li < sh.vc.nlist; ++li) {
-      const ListEntry le = sh.vc.lst[li].le;
-      const Group g = sh.vc.lst[li].g;
-      const bool self = le.flags & LF_SELF;
-      if (g.spec == 0xFF) {
-        if (!topo_host(S, P, g, self, hslot)) { *reason |= 4; return false; }
-        continue;
-      }
-      uint64_t podDom = ((uint64_t)le.poddom_hi << 32) | le.poddom_lo;
-      uint64_t nodeDom = ~0ull;
-#pragma unroll
-      for (int i = 0; i < KG_MAXSPEC; ++i) if (i == g.spec) nodeDom = has_mask1(P, sh.spec_slot[i], x.sp[i]);
-      TopoOut o = topo_small(P, S, g, le.g, self, podDom, nodeDom);
-      if (!o.ok) { *reason |= 4; return false; }
-#pragma unroll
-      for (int i = 0; i < KG_MAXSPEC; ++i) if (i == g.spec) { topo[i] &= o.opts; has_topo |= 1u << i; }
-    }
-#pragma unroll
-    for (int i = 0; i < KG_MAXSPEC; ++i) {
-      if (i < P.nspec && ((has_topo >> i) & 1)) {
-        const int a = sh.spec_slot[i];
-        SReq inc{rm_make(false, 0, 0), topo[i]};
-        if (!(x.sp[i].meta & RM_PRESENT)) {
-          // receiver lacks the key: allowed when well-known or the incoming operator is DoesNotExist
-          if (!((P.well_known_slots >> a) & 1) && topo[i] != 0) { *reason |= 4; return false; }
-          x.sp[i] = inc;
-          x.sp_changed |= 1u << i;
-        } else {
-          SReq r = intersect1(P, a, x.sp[i], inc);  // incoming as AddRequirements builds it: node ∩ domains
-          const bool empty = !(r.meta & RM_COMPL) && r.word == 0;
-          const int eop = opclass(x.sp[i].meta & RM_COMPL, x.sp[i].word != 0);
-          if (empty && !op_neg(eop)) { *reason |= 4; return false; }  // incoming is DoesNotExist-class when empty
-          if (r.word != x.sp[i].word || r.meta != x.sp[i].meta) x.sp_changed |= 1u << i;
-          x.sp[i] = r;
-        }
-        if (COMMIT) {
-          S.c_bits[(size_t)sh.aoff[a] * P.Cmax + c] = x.sp[i].word;
-          S.c_meta[(size_t)a * P.Cmax + c] = x.sp[i].meta;
-        }
-      }
-    }
-  }
-  // step C (scalar half): requests -> fit thresholds; merged zone / capacity-type -> offering selection
-  x.thr_use = 0;
-  const int64_t* tv = sh.thr_lds ? sh.thr_val : P.thr_val;
-#pragma unroll
-  for (int r = 0; r < KG_MAXR; ++r) {
-    x.thr_idx[r] = 0; x.newreq[r] = 0;
-    if (r < P.R) {
-      const int64_t add = sh.preq[r];
-      if (add != 0 || fresh) {
-        x.newreq[r] = S.c_req[(size_t)r * P.Cmax + c] + add;
-        if (x.newreq[r] > 0) {
-          x.thr_use |= 1u << r;
-          x.thr_idx[r] = thr_lookup_ge(tv + (sh.thr_lds ? sh.thr_base[r] : P.a_thr_off[r]), (int)P.a_thr_n[r], x.newreq[r]);
-        }
-      }
-    }
-  }
-  x.off_use = fresh;
-  x.zmask = ~0ull; x.ctmask = ~0ull;
-#pragma unroll
-  for (int i = 0; i < KG_MAXSPEC; ++i) {
-    if (i < P.nspec) {
-      if (i == P.slot_zone || i == P.slot_ct || i == P.slot_zid) x.off_use = x.off_use || ((x.sp_changed >> i) & 1);
-      const uint64_t hm = has_mask1(P, sh.spec_slot[i], x.sp[i]);
-      if (i == P.slot_zone) x.zmask &= hm;
-      if (i == P.slot_ct) x.ctmask = hm;
-      if (i == P.slot_zid) {
-        uint64_t zm = 0;
-        for (int z = 0; z < P.n_zone_vals; ++z) {
-          uint8_t zid = P.zone_zid[z];
-          if (zid == 0xFF || ((hm >> zid) & 1)) zm |= 1ull << z;
-        }
-        x.zmask &= zm;
-      }
-      if ((x.sp[i].meta & RM_PRESENT) && op_neg(opclass(x.sp[i].meta & RM_COMPL, x.sp[i].word != 0))) x.sp_dne_ok |= 1u << i;
-    }
-  }
-  x.minv = P.tmpl_minv_off[tmpl + 1] > P.tmpl_minv_off[tmpl];
-  return true;
+KG_HD SReq row_special(const Shared& sh, const Row& R, int i) {
+  const int a = sh.spec_slot[i];
+  SReq r;
+  r.meta = R.meta[a];
+  r.word = (r.meta & RM_PRESENT) ? R.bits[sh.aoff[a]] : 0;
+  return r;
 }
 
-// filterInstanceTypesByRequirements in type-mask space: word w of the claim's remaining options after the pod.
-KG_HD uint64_t claim_word(const DevProblem& P, const SimState& S, const Shared& sh, const ClaimCtx& x, uint32_t c, int w) {
-  uint64_t m = S.c_mask[(size_t)w * P.Cmax + c];
+// Requirement.Intersection of row slot a (w words at off) with (pm, pb), in place.  Returns the merged meta.
+KG_HD uint32_t row_intersect(const DevProblem& P, Row& R, int a, int w, int off, uint32_t pm, const uint64_t* pb, bool* any, bool* changed,
+                             bool* cany) {
+  const uint32_t cm = R.meta[a];
+  const bool xc = cm & RM_COMPL, yc = pm & RM_COMPL;
+  const uint32_t gt = rm_gt(cm) > rm_gt(pm) ? rm_gt(cm) : rm_gt(pm);
+  const uint32_t lt = min_nz(rm_lt(cm), rm_lt(pm));
+  const bool dne = gt && lt && P.gtval[P.bnd_off[a] + gt - 1] >= P.ltval[P.bnd_off[a] + lt - 1];
+  const bool c2 = xc && yc && !dne;
+  const uint32_t meta = c2 ? rm_make(true, gt, lt) : rm_make(false, 0, 0);
+  bool anyb = false, chg = meta != cm, canyb = false;
+  for (int i = 0; i < w; ++i) {
+    const uint64_t x = R.bits[off + i], y = pb[i];
+    canyb |= x != 0;
+    uint64_t r = dne ? 0 : ((xc && yc) ? (x | y) : (xc ? (y & ~x) : (yc ? (x & ~y) : (x & y))));
+    if (!dne && gt) r &= P.gtmask[P.bndmask_off[a] + (size_t)(gt - 1) * w + i];
+    if (!dne && lt) r &= P.ltmask[P.bndmask_off[a] + (size_t)(lt - 1) * w + i];
+    anyb |= r != 0;
+    chg |= r != x;
+    R.bits[off + i] = r;
+  }
+  R.meta[a] = meta;
+  *any = anyb;
+  *changed = chg;
+  *cany = canyb;
+  return meta;
+}
+
+// Step 3 of NodeClaim.Add for ONE pod requirement entry j: Requirements.Compatible(podReqs) + Add on that key.
+// Entries of one requirement set are on distinct keys, so the entries of a pod merge in parallel.
+KG_HD void row_merge_entry(const DevProblem& P, const Shared& sh, Row& R, uint32_t j, bool fresh) {
+  const PodEntry pe = sh.vc.ent[j];
+  const int a = pe.slot;
+  const uint64_t* pb = entry_bits(P, sh, pe);
+  const uint32_t cm = R.meta[a];
+  if (!(cm & RM_PRESENT)) {
+    if (!((P.well_known_slots >> a) & 1) && !op_neg(pe.opc)) { R.ok = 0; atomic_or_u32(&R.reason, 2u); return; }
+    if (op_neg(pe.opc)) atomic_or_u32(&R.ent_dne_ok, 1u << j);
+    atomic_or_u32(&R.ent_changed, 1u << j);
+    if (pe.spec >= 0) atomic_or_u32(&R.sp_changed, 1u << pe.spec);
+    for (int i = 0; i < pe.w; ++i) R.bits[pe.aoff + i] = pb[i];
+    R.meta[a] = pe.meta;
+    return;
+  }
+  bool anyb, chg, canyb;
+  const uint32_t mm = row_intersect(P, R, a, pe.w, pe.aoff, pe.meta, pb, &anyb, &chg, &canyb);
+  const int cop = opclass(cm & RM_COMPL, canyb);
+  const bool empty = !(mm & RM_COMPL) && !anyb;
+  if (empty && !(op_neg(pe.opc) && op_neg(cop))) { R.ok = 0; atomic_or_u32(&R.reason, 2u); return; }
+  if (op_neg(opclass(mm & RM_COMPL, anyb))) atomic_or_u32(&R.ent_dne_ok, 1u << j);
+  if (chg || fresh) atomic_or_u32(&R.ent_changed, 1u << j);
+  if (pe.spec >= 0 && chg) atomic_or_u32(&R.sp_changed, 1u << pe.spec);
+}
+
+// Step 5 for ONE active resource: requests including the pod, and the fit threshold they select.
+KG_HD void row_merge_resource(const DevProblem& P, const Shared& sh, Row& R, int r, bool fresh) {
+  const int64_t add = sh.preq[r];
+  if (add == 0 && !fresh) return;
+  const int64_t nr = R.req[r] + add;
+  R.req[r] = nr;
+  if (nr > 0) {
+    const int64_t* tv = sh.thr_lds ? sh.thr_val + sh.thr_base[r] : P.thr_val + P.a_thr_off[r];
+    R.thr_idx[r] = thr_lookup_ge(tv, (int)P.a_thr_n[r], nr);
+    atomic_or_u32(&R.thr_use, 1u << r);
+  }
+}
+
+// Step 4: Topology.AddRequirements -> Compatible -> Add, on the special keys of the row (one thread per row).
+KG_HD void row_topology(const DevProblem& P, const SimState& S, const Shared& sh, Row& R) {
+  const uint32_t hslot = P.N + R.c;
+  for (int i = 0; i < P.nspec; ++i) R.topo[i] = ~0ull;
+  uint32_t has_topo = 0;
+  for (uint32_t li = 0; li < sh.vc.nlist; ++li) {
+    const ListEntry le = sh.vc.lst[li].le;
+    const Group g = sh.vc.lst[li].g;
+    const bool self = le.flags & LF_SELF;
+    if (g.spec == 0xFF) {
+      if (!topo_host(S, P, g, self, hslot)) { R.ok = 0; R.reason |= 4; return; }
+      continue;
+    }
+    const uint64_t podDom = ((uint64_t)le.poddom_hi << 32) | le.poddom_lo;
+    const uint64_t nodeDom = has_mask1(P, sh.spec_slot[g.spec], row_special(sh, R, g.spec));
+    TopoOut o = topo_small(P, S, g, le.g, self, podDom, nodeDom);
+    if (!o.ok) { R.ok = 0; R.reason |= 4; return; }
+    R.topo[g.spec] &= o.opts;
+    has_topo |= 1u << g.spec;
+  }
+  for (int i = 0; i < P.nspec; ++i) {
+    if (!((has_topo >> i) & 1)) continue;
+    const int a = sh.spec_slot[i];
+    const SReq cur = row_special(sh, R, i);
+    SReq inc{rm_make(false, 0, 0), R.topo[i]};
+    SReq out;
+    if (!(cur.meta & RM_PRESENT)) {
+      // receiver lacks the key: allowed when well-known or the incoming operator is DoesNotExist
+      if (!((P.well_known_slots >> a) & 1) && inc.word != 0) { R.ok = 0; R.reason |= 4; return; }
+      out = inc;
+      R.sp_changed |= 1u << i;
+    } else {
+      out = intersect1(P, a, cur, inc);  // incoming as AddRequirements builds it: node ∩ domains
+      const bool empty = !(out.meta & RM_COMPL) && out.word == 0;
+      const int eop = opclass(cur.meta & RM_COMPL, cur.word != 0);
+      if (empty && !op_neg(eop)) { R.ok = 0; R.reason |= 4; return; }  // incoming is DoesNotExist-class when empty
+      if (out.word != cur.word || out.meta != cur.meta) R.sp_changed |= 1u << i;
+    }
+    R.bits[sh.aoff[a]] = out.word;
+    R.meta[a] = out.meta;
+  }
+}
+
+// Step 6: filterInstanceTypesByRequirements in type-mask space: word w of the claim's remaining options after the pod.
+KG_HD uint64_t row_word(const DevProblem& P, const SimState& S, const Shared& sh, const Row& R, bool fresh, int w) {
+  uint64_t m = S.c_mask[(size_t)w * P.Cmax + R.c];
   const uint32_t ne = sh.vc.ne;
   // pod entries on ordinary keys
-#pragma unroll
-  for (int j = 0; j < KG_MAXE; ++j) {
-    if ((uint32_t)j < ne && ((x.ent_changed >> j) & 1)) {
-      const PodEntry pe = sh.vc.ent[j];
-      if (pe.spec < 0) {
-        uint64_t f = P.e_amask[(size_t)pe.e * P.TW + w];
-        if ((x.ent_dne_ok >> j) & 1) f |= P.kU[(size_t)pe.slot * P.TW + w];
-        m &= f;
-      }
-    }
+  for (uint32_t j = 0; j < ne; ++j) {
+    if (!((R.ent_changed >> j) & 1)) continue;
+    const PodEntry pe = sh.vc.ent[j];
+    if (pe.spec >= 0) continue;
+    uint64_t f = P.e_amask[(size_t)pe.e * P.TW + w];
+    if ((R.ent_dne_ok >> j) & 1) f |= P.kU[(size_t)pe.slot * P.TW + w];
+    m &= f;
   }
-  if (x.fresh) {
+  if (fresh) {
     // template entries on ordinary keys (merged operator class was computed if the pod shares the key)
-    for (uint32_t k = 0; k < x.nt; ++k) {
-      const uint32_t e = x.t0 + k;
+    const uint32_t t0 = P.rs_off[P.tmpl_rs[R.tmpl]], t1 = P.rs_off[P.tmpl_rs[R.tmpl] + 1];
+    for (uint32_t e = t0; e < t1; ++e) {
       const int a = P.e_slot[e];
       if (sh.slot2spec[a] >= 0) continue;
       uint64_t f = P.e_amask[(size_t)e * P.TW + w];
       bool shared = false, dne_ok = false;
-#pragma unroll
-      for (int j = 0; j < KG_MAXE; ++j)
-        if ((uint32_t)j < ne && sh.vc.ent[j].slot == a) { shared = true; dne_ok = (x.ent_dne_ok >> j) & 1; }
+      for (uint32_t j = 0; j < ne; ++j)
+        if (sh.vc.ent[j].slot == a) { shared = true; dne_ok = (R.ent_dne_ok >> j) & 1; }
       if (!shared) {
         const uint64_t* tb = P.rs_bits + P.e_bits[e];
         bool anyb = false;
@@ -641,38 +549,51 @@ KG_HD uint64_t claim_word(const DevProblem& P, const SimState& S, const Shared& 
       m &= f;
     }
   }
-  // special keys: types whose value set meets the merged allowed set
-#pragma unroll
-  for (int i = 0; i < KG_MAXSPEC; ++i) {
-    if (i < P.nspec && ((x.sp_changed >> i) & 1) && (x.sp[i].meta & RM_PRESENT)) {
-      const int a = sh.spec_slot[i];
-      uint64_t hm = has_mask1(P, a, x.sp[i]);
+  // special keys: types whose value set meets the merged allowed set; offering selection from zone / capacity type
+  bool off_use = fresh;
+  uint64_t zmask = ~0ull, ctmask = ~0ull;
+  for (int i = 0; i < P.nspec; ++i) {
+    const int a = sh.spec_slot[i];
+    const SReq sp = row_special(sh, R, i);
+    const bool present = sp.meta & RM_PRESENT;
+    const bool changed = ((R.sp_changed >> i) & 1) || (fresh && present);
+    const uint64_t hm = has_mask1(P, a, sp);
+    if (changed && present) {
       uint64_t f = P.kN[(size_t)a * P.TW + w];
-      if ((x.sp_dne_ok >> i) & 1) f |= P.kU[(size_t)a * P.TW + w];
+      if (op_neg(opclass(sp.meta & RM_COMPL, sp.word != 0))) f |= P.kU[(size_t)a * P.TW + w];
       const int nv = P.ktwv_n[a];
       for (uint64_t mm = hm; mm; mm &= mm - 1) {
-        int d = ctz64(mm);
+        const int d = ctz64(mm);
         if (d < nv) f |= P.twv[((size_t)P.ktwv_off[a] + d) * P.TW + w];
       }
       m &= f;
     }
-  }
-  // fits
-#pragma unroll
-  for (int r = 0; r < KG_MAXR; ++r) {
-    if ((x.thr_use >> r) & 1) {
-      if (x.thr_idx[r] >= (int)P.a_thr_n[r]) m = 0;
-      else m &= P.thr_mask[((size_t)P.a_thr_off[r] + x.thr_idx[r]) * P.TW + w];
+    if (i == P.slot_zone || i == P.slot_ct || i == P.slot_zid) off_use = off_use || changed;
+    if (i == P.slot_zone) zmask &= hm;
+    if (i == P.slot_ct) ctmask = hm;
+    if (i == P.slot_zid) {
+      uint64_t zm = 0;
+      for (int z = 0; z < P.n_zone_vals; ++z) {
+        const uint8_t zid = P.zone_zid[z];
+        if (zid == 0xFF || ((hm >> zid) & 1)) zm |= 1ull << z;
+      }
+      zmask &= zm;
     }
   }
-  if (x.fresh) m &= P.valid_types[w];
+  // fits
+  for (int r = 0; r < P.R; ++r) {
+    if (!((R.thr_use >> r) & 1)) continue;
+    if (R.thr_idx[r] >= (int)P.a_thr_n[r]) m = 0;
+    else m &= P.thr_mask[((size_t)P.a_thr_off[r] + R.thr_idx[r]) * P.TW + w];
+  }
+  if (fresh) m &= P.valid_types[w];
   // hasOffering
-  if (x.off_use) {
+  if (off_use) {
     uint64_t f = 0;
     for (int z = 0; z < P.n_zone_vals; ++z) {
-      if (!((x.zmask >> z) & 1)) continue;
+      if (!((zmask >> z) & 1)) continue;
       for (int ct = 0; ct < P.n_ct_vals; ++ct)
-        if ((x.ctmask >> ct) & 1) f |= P.offmask[((size_t)z * 4 + ct) * P.TW + w];
+        if ((ctmask >> ct) & 1) f |= P.offmask[((size_t)z * 4 + ct) * P.TW + w];
     }
     m &= f;
   }
@@ -694,30 +615,54 @@ KG_HD bool claim_minvalues_ok(const DevProblem& P, const SimState& S, uint32_t t
   return true;
 }
 
-// Commit tail of NodeClaim.Add (after claim_prepare<true> and the option mask copy): requests, pod count, Topology.Record.
-KG_HD void claim_commit_tail(const DevProblem& P, const SimState& S, const Shared& sh, const ClaimCtx& x, uint32_t c) {
-#pragma unroll
-  for (int r = 0; r < KG_MAXR; ++r) {
-    if (r < P.R && (sh.preq[r] != 0 || x.fresh)) {
-      S.c_req[(size_t)r * P.Cmax + c] = x.newreq[r];
-      if (!x.fresh) S.c_head[(size_t)r * P.Cmax + c] -= sh.preq[r];
+// Requirements.Compatible(row, requirement set rs, AllowUndefinedWellKnownLabels) without merging (Topology.Record's node filter)
+KG_HD bool row_compatible_rs(const DevProblem& P, const Shared& sh, const Row& R, uint32_t rs) {
+  for (uint32_t e = P.rs_off[rs]; e < P.rs_off[rs + 1]; ++e) {
+    const int a = P.e_slot[e];
+    const uint32_t pm = P.e_meta[e];
+    const uint64_t* pb = P.rs_bits + P.e_bits[e];
+    const int w = sh.aw[a], off = sh.aoff[a];
+    bool panyb = false;
+    for (int i = 0; i < w; ++i) panyb |= pb[i] != 0;
+    const int pop = opclass(pm & RM_COMPL, panyb);
+    const uint32_t cm = R.meta[a];
+    if (!(cm & RM_PRESENT)) {
+      if (!((P.well_known_slots >> a) & 1) && !op_neg(pop)) return false;
+      continue;
     }
+    const bool xc = cm & RM_COMPL, yc = pm & RM_COMPL;
+    const uint32_t gt = rm_gt(cm) > rm_gt(pm) ? rm_gt(cm) : rm_gt(pm);
+    const uint32_t lt = min_nz(rm_lt(cm), rm_lt(pm));
+    const bool dne = gt && lt && P.gtval[P.bnd_off[a] + gt - 1] >= P.ltval[P.bnd_off[a] + lt - 1];
+    bool anyb = false, canyb = false;
+    for (int i = 0; i < w; ++i) {
+      const uint64_t x = R.bits[off + i], y = pb[i];
+      canyb |= x != 0;
+      uint64_t r = dne ? 0 : ((xc && yc) ? (x | y) : (xc ? (y & ~x) : (yc ? (x & ~y) : (x & y))));
+      if (!dne && gt) r &= P.gtmask[P.bndmask_off[a] + (size_t)(gt - 1) * w + i];
+      if (!dne && lt) r &= P.ltmask[P.bndmask_off[a] + (size_t)(lt - 1) * w + i];
+      anyb |= r != 0;
+    }
+    const bool empty = !(xc && yc && !dne) && !anyb;
+    if (empty && !(op_neg(pop) && op_neg(opclass(xc, canyb)))) return false;
   }
-  S.c_npods[c] += 1;
+  return true;
+}
+
+// Topology.Record for a pod placed on the claim of row R (after the commit of its requirements)
+KG_HD void row_record_topology(const DevProblem& P, const SimState& S, const Shared& sh, const Row& R) {
   const Variant& v = sh.vc.v;
-  const uint32_t hslot = P.N + c;
+  const uint32_t hslot = P.N + R.c;
   for (uint32_t li = 0; li < v.record_cnt; ++li) {
     const ListEntry le = P.lists[v.record_off + li];
     const Group g = P.groups[le.g];
     if (!(le.flags & LF_INVERSE) && g.filter_cnt) {
       bool match = false;
-      for (uint32_t f = 0; f < g.filter_cnt && !match; ++f) match = claim_compatible_rs(P, S, c, P.filters[g.filter_off + f]);
+      for (uint32_t f = 0; f < g.filter_cnt && !match; ++f) match = row_compatible_rs(P, sh, R, P.filters[g.filter_off + f]);
       if (!match) continue;
     }
     if (g.spec == 0xFF) { record_host(S, P, g, hslot); continue; }
-    SReq r{0, 0};
-#pragma unroll
-    for (int i = 0; i < KG_MAXSPEC; ++i) if (i == g.spec) r = x.sp[i];
+    const SReq r = row_special(sh, R, g.spec);
     if (!(r.meta & RM_PRESENT)) continue;
     if ((le.flags & LF_INVERSE) || g.type == TG_ANTI) {
       for (uint64_t mm = r.word; mm; mm &= mm - 1) record_small(S, le.g, ctz64(mm));
@@ -727,9 +672,8 @@ KG_HD void claim_commit_tail(const DevProblem& P, const SimState& S, const Share
   }
 }
 
-// max allocatable per active resource over the option mask of claim c, minus its requests: the prefilter's headroom.
-// One thread per (resource, word); combined through LDS-free global atomics is overkill: a single thread per resource
-// walks the (short) mask.  Called when a claim is created and when the prefilter let an infeasible claim through.
+// max allocatable of active resource r over the option mask of claim c, minus its requests: the prefilter's headroom.
+// Computed when a claim is created and when the prefilter let an infeasible claim through.
 KG_HD void claim_refresh_head(const DevProblem& P, const SimState& S, uint32_t c, int r) {
   int64_t mx = 0;
   const int64_t* al = P.alloc + (size_t)P.a_res[r] * P.T;
@@ -787,15 +731,23 @@ KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, u
 
 // ------------------------------------------------------------------ one Solve by one workgroup
 // NT = threads in the workgroup.  `sh` lives in LDS.
+//
+// Barrier discipline: a value in LDS that steers uniform control flow (a loop condition, a branch around barriers) is
+// only ever written in a phase that is followed by a barrier AND is at least one barrier after the last uniform read
+// of it -- otherwise a fast wave overwrites it while a slow wave has not branched yet, and the waves' barrier counts
+// diverge.
 template <int NT>
 KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint32_t n_queue) {
-  const bool STATS = P.stats != 0;
-  const uint32_t TWP = (uint32_t)P.TWP;      // threads per evaluation group (power of two >= TW)
-  const uint32_t GP = NT / TWP;              // survivors evaluated per pass
+  const bool STATS = (P.stats & 1) != 0;
+  const bool TIMERS = (P.stats & 2) != 0;  // per-phase wall-clock ticks (100 MHz) of thread 0 into counters[8..]
+  unsigned long long t_mark = 0;
+#define KG_T(i) do { if (TIMERS) { KG_FOR_THREADS(tid, NT) { if (tid == 0) { const unsigned long long n_ = now_ticks(); if (t_mark) S.counters[8 + (i)] += n_ - t_mark; t_mark = n_; } } } } while (0)
+  const uint32_t TWP = (uint32_t)P.TWP;      // threads per evaluation group (power of two >= max(TW, 16))
+  const uint32_t GP = (NT / TWP) < (uint32_t)KG_MAXGP ? (NT / TWP) : (uint32_t)KG_MAXGP;  // survivors evaluated per pass
   // ---- stage the small problem tables in LDS
   KG_FOR_THREADS(tid, NT) {
     if (tid == 0) {
-      sh.qhead = 0; sh.qlen = n_queue; sh.epoch = 1; sh.nclaims = S.header[0]; sh.done = 0; sh.hostname_ctr = 0; sh.seq = 0; sh.last_c = KG_NOIDX; sh.last_new = 0;
+      sh.qhead = 0; sh.qlen = n_queue; sh.epoch = 1; sh.nclaims = S.header[0]; sh.done = 0; sh.seq = 0; sh.last_c = KG_NOIDX; sh.last_new = 0;
       uint32_t tot = 0;
       for (int r = 0; r < P.R; ++r) { sh.thr_base[r] = tot; tot += P.a_thr_n[r]; }
       sh.thr_lds = tot <= (uint32_t)KG_THR_LDS;
@@ -833,7 +785,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     }
     KG_SYNC();
     if (sh.done) break;
-    // ---- pod context: one coalesced copy of the variant's precompiled record + the pod's requests
+    // ---- pod context: one coalesced copy of the variant's precompiled record + its type mask + the pod's requests
     KG_FOR_THREADS(tid, NT) {
       const uint64_t* src = (const uint64_t*)(P.vctx + sh.variant);
       uint64_t* dst = (uint64_t*)&sh.vc;
@@ -842,8 +794,14 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
         const int r = tid - (NT - KG_MAXR);
         sh.preq[r] = r < P.R ? P.preq[(size_t)sh.pod * P.R + r] : 0;
       }
+      if (tid >= NT / 2 && tid < NT / 2 + P.TW && P.TW <= KG_TWLDS) sh.podmask[tid - NT / 2] = P.podmask[(size_t)sh.variant * P.TW + (tid - NT / 2)];
+      // (sh.placed & co are reset here, a barrier after the last uniform read of them, not in Queue.Pop)
+      // The reference sorts newNodeClaims at the start of the claim stage of every add(); what happens after (one pod
+      // added to a claim, or one claim appended) is not re-sorted, and Results returns the slice as it stands.
+      if (tid == 0) { sh.bestkey = ~0ull; sh.scan_base = 0; sh.placed = 0; sh.stage = 0; sh.tnext = 0; sh.result = 0; sh.winner = KG_NOIDX; }
     }
     KG_SYNC();
+    KG_T(0);
     // ---- existing nodes, first feasible in scan order
     for (uint32_t base = 0; base < (uint32_t)P.N; base += NT) {
       KG_FOR_THREADS(tid, NT) {
@@ -864,140 +822,255 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
           S.pod_kind[sh.pod] = 1;
           S.pod_index[sh.pod] = (int32_t)sh.best;
           if (STATS) S.counters[0] += sh.best + 1;
-          sh.placed = 1;
         }
       }
       KG_SYNC();
       continue;
     }
     if (STATS) {
-      KG_FOR_THREADS(tid, NT) { if (tid == 0) S.counters[0] += P.N; }
+      KG_FOR_THREADS(tid, NT) { if (tid == 0) { S.counters[0] += P.N; sh.st_vis = 0; sh.st_types = 0; } }
     }
-    // ---- in-flight NodeClaims: first feasible in (pod count, stable) order = minimum claim_key.
-    // Rounds of: prefilter a range of claims into the survivor list -> order the survivors -> exact NodeClaim.Add on
-    // them, GP at a time, until one accepts the pod.  A later round only looks for keys below the best so far.
-    KG_FOR_THREADS(tid, NT) {
-      // (sh.placed is reset here, two barriers after the last uniform read of it, not in Queue.Pop)
-      // The reference sorts newNodeClaims at this point of every add(); what happens after (one pod added to a claim,
-      // or one claim appended) is not re-sorted, and Results returns the slice as it stands: remember that one change.
-      if (tid == 0) { sh.bestkey = ~0ull; sh.scan_base = 0; sh.placed = 0; sh.last_c = KG_NOIDX; sh.last_new = 0; }
-    }
-    KG_SYNC();
-    while (sh.scan_base < sh.nclaims) {
-      KG_FOR_THREADS(tid, NT) { if (tid == 0) sh.nsurv = 0; }
-      KG_SYNC();
-      // prefilter: conservative, coalesced over claims
-      const uint32_t round_base = sh.scan_base;
-      uint32_t round_end = round_base;
-      for (; round_end < sh.nclaims && round_end + NT <= round_base + (uint32_t)KG_MAXSURV; round_end += NT) {
-        KG_FOR_THREADS(tid, NT) {
-          const uint32_t c = round_end + tid;
-          if (c < sh.nclaims) {
-            bool ok = ((P.tol_tmpl[sh.vc.v.tolset] >> S.c_tmpl[c]) & 1) && sh.vc.v.host_claim_ok;
-            for (int r = 0; ok && r < P.R; ++r) ok = sh.preq[r] == 0 || S.c_head[(size_t)r * P.Cmax + c] >= sh.preq[r];
-            if (ok) {
-              uint64_t any = 0;
-              const uint64_t* pm = P.podmask + (size_t)sh.variant * P.TW;
-              for (int w = 0; w < P.TW; ++w) any |= S.c_mask[(size_t)w * P.Cmax + c] & pm[w];
-              ok = any != 0;
-            }
-            if (ok) {
-              const unsigned long long key = claim_key(S.c_npods[c], S.c_stamp[c], c);
-              if (key < sh.bestkey) {
-                const uint32_t i = atomic_inc_u32(&sh.nsurv);
-                sh.surv[i] = c;
-                sh.skey[i] = key;
+    KG_T(1);
+    // ---- in-flight NodeClaims (stage 0), then a new NodeClaim from each template in weight order (stage 1).
+    // Stage 0 finds the first feasible claim in (pod count, stable) order = minimum claim_key, in rounds of:
+    // prefilter a range of claims into the survivor list -> order the survivors -> exact NodeClaim.Add on them, GP at
+    // a time, until one accepts the pod; a later round only looks for keys below the best so far.  Stage 1 runs the
+    // same NodeClaim.Add on one freshly materialised claim per template.
+    KG_FOR_THREADS(tid, NT) { if (tid == 0) { sh.last_c = KG_NOIDX; sh.last_new = 0; } }
+    while (true) {
+      const uint32_t stage = sh.stage;
+      if (stage == 2) break;
+      const bool fresh = stage == 1;
+      uint32_t ns = 0;
+      if (!fresh) {
+        KG_FOR_THREADS(tid, NT) { if (tid == 0) sh.nsurv = 0; }
+        KG_SYNC();
+        // prefilter: conservative, coalesced over claims.  With the visit counters on, every claim is evaluated exactly.
+        const uint32_t round_base = sh.scan_base;
+        uint32_t round_end = round_base;
+        for (; round_end < sh.nclaims && round_end + NT <= round_base + (uint32_t)KG_MAXSURV; round_end += NT) {
+          KG_FOR_THREADS(tid, NT) {
+            const uint32_t c = round_end + tid;
+            if (c < sh.nclaims) {
+              bool ok = true;
+              if (!STATS) {
+                ok = ((P.tol_tmpl[sh.vc.v.tolset] >> S.c_tmpl[c]) & 1) && sh.vc.v.host_claim_ok;
+                for (int r = 0; ok && r < P.R; ++r) ok = sh.preq[r] == 0 || S.c_head[(size_t)r * P.Cmax + c] >= sh.preq[r];
+                if (ok) {
+                  uint64_t any = 0;
+                  if (P.TW <= KG_TWLDS) {
+                    for (int w = 0; w < P.TW; ++w) any |= S.c_mask[(size_t)w * P.Cmax + c] & sh.podmask[w];
+                  } else {
+                    const uint64_t* pm = P.podmask + (size_t)sh.variant * P.TW;
+                    for (int w = 0; w < P.TW; ++w) any |= S.c_mask[(size_t)w * P.Cmax + c] & pm[w];
+                  }
+                  ok = any != 0;
+                }
+              }
+              if (ok) {
+                const unsigned long long key = claim_key(S.c_npods[c], S.c_stamp[c], c);
+                if (key < sh.bestkey) {
+                  const uint32_t i = atomic_inc_u32(&sh.nsurv);
+                  sh.surv[i] = c;
+                  sh.skey[i] = key;
+                }
               }
             }
           }
+          KG_SYNC();
+        }
+        KG_T(2);
+        // order the survivors by key (rank by counting; keys are unique)
+        ns = sh.nsurv;
+        KG_FOR_THREADS(tid, NT) {
+          for (uint32_t i = tid; i < ns; i += NT) {
+            const unsigned long long k = sh.skey[i];
+            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            uint32_t j = 0;
+            for (; j + 4 <= ns; j += 4) { r0 += sh.skey[j] < k; r1 += sh.skey[j + 1] < k; r2 += sh.skey[j + 2] < k; r3 += sh.skey[j + 3] < k; }
+            for (; j < ns; ++j) r0 += sh.skey[j] < k;
+            sh.sorted[r0 + r1 + r2 + r3] = sh.surv[i];
+          }
+          if (tid == 0) { sh.scan_base = round_end < sh.nclaims ? round_end : sh.nclaims; sh.pass_lo = 0; sh.winner = KG_NOIDX; }
         }
         KG_SYNC();
-      }
-      KG_FOR_THREADS(tid, NT) { if (tid == 0) sh.scan_base = round_end < sh.nclaims ? round_end : sh.nclaims; }
-      // order the survivors by key (rank by counting; keys are unique)
-      const uint32_t ns = sh.nsurv;
-      KG_FOR_THREADS(tid, NT) {
-        for (uint32_t i = tid; i < ns; i += NT) {
-          const unsigned long long k = sh.skey[i];
-          uint32_t rank = 0;
-          for (uint32_t j = 0; j < ns; ++j) rank += sh.skey[j] < k;
-          sh.sorted[rank] = sh.surv[i];
+        KG_T(3);
+        if (TIMERS) { KG_FOR_THREADS(tid, NT) { if (tid == 0) { S.counters[20] += ns; S.counters[21] += 1; } } }
+      } else {
+        // filterByRemainingResources + NewNodeClaim: materialise claim c = nclaims from template t into rows[0]
+        const uint32_t c = sh.nclaims;
+        const int t = (int)sh.tnext;
+        KG_FOR_THREADS(tid, NT) {
+          Row& R = sh.rows[0];
+          if (tid == 0) {
+            sh.fresh_lim = 0;
+            R.c = c; R.tmpl = (uint32_t)t; R.reason = 0; R.feas = 0; R.tv = 0; R.ent_changed = 0; R.ent_dne_ok = 0; R.sp_changed = 0; R.thr_use = 0;
+            R.ok = ((P.tol_tmpl[sh.vc.v.tolset] >> t) & 1) && sh.vc.v.host_claim_ok;
+            if (!R.ok) R.reason = ((P.tol_tmpl[sh.vc.v.tolset] >> t) & 1) ? 2u : 1u;
+            sh.sorted[0] = c; sh.pass_lo = 0; sh.winner = KG_NOIDX;
+          }
+          for (int a = tid; a < P.Ka; a += NT) R.meta[a] = 0;
+          for (int i = tid; i < P.Wa; i += NT) R.bits[i] = 0;
+          for (int r = tid; r < KG_MAXR; r += NT) R.req[r] = r < P.R ? P.tmpl_req[(size_t)r * P.NP + t] : 0;
+          // hostname placeholder registered for this attempt: hcount rows of slot N+c start at zero
+          for (int gh = tid; gh < P.GH; gh += NT) S.hcount[(size_t)gh * P.H + P.N + c] = 0;
         }
-        if (tid == 0) { sh.pass_lo = 0; sh.winner = KG_NOIDX; }
-      }
-      KG_SYNC();
-      // exact evaluation in scan order, GP survivors per pass, TWP threads each
-      while (sh.pass_lo < ns && sh.winner == KG_NOIDX) {
-        const uint32_t lo = sh.pass_lo;
-        KG_FOR_THREADS(tid, NT) { if ((uint32_t)tid < GP) sh.sfeas[tid] = 0; }
         KG_SYNC();
         KG_FOR_THREADS(tid, NT) {
-          const uint32_t gi = (uint32_t)tid / TWP, w = (uint32_t)tid % TWP;
-          if (lo + gi < ns && w < (uint32_t)P.TW) {
-            const uint32_t c = sh.sorted[lo + gi];
-            ClaimCtx x;
-            uint32_t reason = 0;
-            if (claim_prepare<false>(P, S, sh, c, false, x, &reason)) {
-              const uint64_t m = claim_word(P, S, sh, x, c, (int)w);
-              S.scratch[(size_t)w * P.Cmax + c] = m;
-              if (m) sh.sfeas[gi] = 1;
+          Row& R = sh.rows[0];
+          for (int w = tid; w < P.TW; w += NT) {
+            uint64_t m = ~0ull;
+            if (w == P.TW - 1 && (P.T & 63)) m = (1ull << (P.T & 63)) - 1;
+            if (P.tmpl_has_limits[t]) {
+              for (int r = 0; r < P.R; ++r) {
+                if (!P.tmpl_limit_res[(size_t)r * P.NP + t]) continue;
+                const int idx = thr_lookup_le(P.cthr_val + P.a_cthr_off[r], (int)P.a_cthr_n[r], S.remaining[(size_t)r * P.NP + t]);
+                if (idx < 0) m = 0; else m &= P.cthr_mask[((size_t)P.a_cthr_off[r] + idx) * P.TW + w];
+              }
             }
+            S.c_mask[(size_t)w * P.Cmax + c] = m;
+            if (m) sh.fresh_lim = 1;
+          }
+          // template requirement entries -> row
+          const uint32_t rs = P.tmpl_rs[t];
+          for (uint32_t e = P.rs_off[rs] + tid; e < P.rs_off[rs + 1]; e += NT) {
+            const int a = P.e_slot[e];
+            R.meta[a] = P.e_meta[e];
+            for (int i = 0; i < sh.aw[a]; ++i) R.bits[sh.aoff[a] + i] = P.rs_bits[P.e_bits[e] + i];
+          }
+        }
+        KG_SYNC();
+        ns = sh.fresh_lim ? 1 : 0;
+      }
+      // ---- exact NodeClaim.Add in scan order: GP claims per pass, TWP threads each
+      while (sh.pass_lo < ns && sh.winner == KG_NOIDX) {
+        const uint32_t lo = sh.pass_lo;
+        if (!fresh) {
+          // load the claims' rows
+          KG_FOR_THREADS(tid, NT) {
+            const uint32_t gi = (uint32_t)tid / TWP, w = (uint32_t)tid % TWP;
+            if (gi < GP && lo + gi < ns) {
+              Row& R = sh.rows[gi];
+              const uint32_t c = sh.sorted[lo + gi];
+              for (int a = (int)w; a < P.Ka; a += (int)TWP) R.meta[a] = S.c_meta[(size_t)a * P.Cmax + c];
+              for (int i = (int)w; i < P.Wa; i += (int)TWP) R.bits[i] = S.c_bits[(size_t)i * P.Cmax + c];
+              if (w < KG_MAXR) R.req[w] = w < (uint32_t)P.R ? S.c_req[(size_t)w * P.Cmax + c] : 0;
+              if (w == TWP - 1) {
+                const uint32_t tm = S.c_tmpl[c];
+                R.c = c; R.tmpl = tm; R.reason = 0; R.feas = 0; R.tv = 0; R.ent_changed = 0; R.ent_dne_ok = 0; R.sp_changed = 0; R.thr_use = 0;
+                R.ok = ((P.tol_tmpl[sh.vc.v.tolset] >> tm) & 1) && sh.vc.v.host_claim_ok;
+              }
+            }
+          }
+          KG_SYNC();
+        }
+        // merge the pod: one thread per requirement entry, one per resource
+        KG_FOR_THREADS(tid, NT) {
+          const uint32_t gi = (uint32_t)tid / TWP, w = (uint32_t)tid % TWP;
+          if (gi < GP && lo + gi < ns && sh.rows[gi].ok) {
+            if (w < sh.vc.ne) row_merge_entry(P, sh, sh.rows[gi], w, fresh);
+            else if (w >= 8 && w < 8 + (uint32_t)P.R) row_merge_resource(P, sh, sh.rows[gi], (int)w - 8, fresh);
+          }
+        }
+        KG_SYNC();
+        if (sh.vc.nlist) {
+          KG_FOR_THREADS(tid, NT) {
+            const uint32_t gi = (uint32_t)tid / TWP, w = (uint32_t)tid % TWP;
+            if (gi < GP && lo + gi < ns && w == 0 && sh.rows[gi].ok) row_topology(P, S, sh, sh.rows[gi]);
+          }
+          KG_SYNC();
+        }
+        // instance-type filter: one thread per 64-type word
+        KG_FOR_THREADS(tid, NT) {
+          const uint32_t gi = (uint32_t)tid / TWP, w = (uint32_t)tid % TWP;
+          if (gi < GP && lo + gi < ns && w < (uint32_t)P.TW && sh.rows[gi].ok) {
+            Row& R = sh.rows[gi];
+            if (STATS) atomic_add_u32(&R.tv, (uint32_t)popc64(S.c_mask[(size_t)w * P.Cmax + R.c]));
+            const uint64_t m = row_word(P, S, sh, R, fresh, (int)w);
+            S.scratch[(size_t)w * P.Cmax + R.c] = m;
+            if (m) R.feas = 1;
           }
         }
         KG_SYNC();
         KG_FOR_THREADS(tid, NT) {
           if (tid == 0) {
+            sh.need_refresh = 0;
             for (uint32_t gi = 0; gi < GP && lo + gi < ns; ++gi) {
-              const uint32_t c = sh.sorted[lo + gi];
-              bool ok = sh.sfeas[gi] != 0;
-              if (ok) {
-                const uint32_t tmpl = S.c_tmpl[c];
-                if (P.tmpl_minv_off[tmpl + 1] > P.tmpl_minv_off[tmpl]) ok = claim_minvalues_ok(P, S, tmpl, c);
+              Row& R = sh.rows[gi];
+              bool ok = R.ok && R.feas;
+              if (ok && P.tmpl_minv_off[R.tmpl + 1] > P.tmpl_minv_off[R.tmpl] && !claim_minvalues_ok(P, S, R.tmpl, R.c)) { ok = false; R.reason |= 32; }
+              if (R.ok && !ok) R.reason |= 8;
+              if (STATS) {
+                if (!fresh) S.scratch[(size_t)P.TW * P.Cmax + R.c] = R.ok ? R.tv : 0;
+                else { S.counters[3] += 1; if (R.ok) S.counters[2] += R.tv; }
               }
-              if (ok) { sh.winner = c; break; }
+              if (ok) { sh.winner = R.c; sh.win_g = gi; break; }
+              if (TIMERS) S.counters[22] += 1;
               // the prefilter let an infeasible claim through: recompute its headroom if its options changed since
-              if (S.c_hstamp[c] != S.c_stamp[c]) { sh.sfeas[gi] = 2; S.c_hstamp[c] = S.c_stamp[c]; }
+              if (!fresh && !STATS && S.c_hstamp[R.c] != S.c_stamp[R.c]) { R.feas = 2; S.c_hstamp[R.c] = S.c_stamp[R.c]; sh.need_refresh = 1; }
             }
             sh.pass_lo = lo + GP;
+            if (TIMERS) S.counters[23] += 1;
           }
         }
         KG_SYNC();
-        // tighten the headroom of false survivors whose options changed since it was last computed
-        KG_FOR_THREADS(tid, NT) {
-          const uint32_t gi = (uint32_t)tid / KG_MAXR;
-          const int r = tid % KG_MAXR;
-          if (gi < GP && lo + gi < ns && r < P.R && sh.sfeas[gi] == 2) {
-            const uint32_t c = sh.sorted[lo + gi];
-            claim_refresh_head(P, S, c, r);
+        if (sh.need_refresh) {
+          // tighten the headroom of false survivors
+          KG_FOR_THREADS(tid, NT) {
+            const uint32_t gi = (uint32_t)tid / KG_MAXR;
+            const int r = tid % KG_MAXR;
+            if (gi < GP && lo + gi < ns && r < P.R && sh.rows[gi].feas == 2) claim_refresh_head(P, S, sh.rows[gi].c, r);
           }
+          KG_SYNC();
+        }
+      }
+      KG_T(4);
+      // ---- verdict of this round / attempt
+      const bool more_rounds = !fresh && sh.scan_base < sh.nclaims;
+      if (more_rounds && sh.winner != KG_NOIDX) {
+        // keep the winner's merged row: later rounds reuse the evaluation groups
+        KG_FOR_THREADS(tid, NT) {
+          const uint64_t* src = (const uint64_t*)&sh.rows[sh.win_g];
+          uint64_t* dst = (uint64_t*)&sh.wrow;
+          for (uint32_t i = tid; i < sizeof(Row) / 8; i += NT) dst[i] = src[i];
         }
         KG_SYNC();
       }
       KG_FOR_THREADS(tid, NT) {
-        if (tid == 0 && sh.winner != KG_NOIDX) {
-          const uint32_t c = sh.winner;
-          sh.bestkey = claim_key(S.c_npods[c], S.c_stamp[c], c);
+        if (tid == 0) {
+          if (!fresh) {
+            if (sh.winner != KG_NOIDX) {
+              const uint32_t c = sh.winner;
+              sh.bestkey = claim_key(S.c_npods[c], S.c_stamp[c], c);
+              sh.result = more_rounds ? 3 : 1;  // 3: the row was parked in wrow
+            }
+            if (!more_rounds) sh.stage = sh.bestkey != ~0ull ? 2 : ((sh.nclaims < (uint32_t)P.Cmax && P.NP > 0) ? 1 : 2);
+          } else {
+            if (sh.winner != KG_NOIDX) { sh.result = 2; sh.stage = 2; }
+            else {
+              sh.reason |= ns ? sh.rows[0].reason : 16u;  // 16: all available instance types exceed limits
+              sh.tnext += 1;
+              if (sh.tnext >= (uint32_t)P.NP) sh.stage = 2;
+            }
+          }
         }
       }
       KG_SYNC();
     }
     if (STATS) {
       // rows the reference visits: every claim up to and including the first feasible one; a visited claim's options
-      // count when the pod got as far as the instance-type filter
-      KG_FOR_THREADS(tid, NT) { if (tid == 0) { sh.st_vis = 0; sh.st_types = 0; } }
-      KG_SYNC();
+      // count when the pod got as far as the instance-type filter (recorded in scratch row TW by the exact pass)
       for (uint32_t base = 0; base < sh.nclaims; base += NT) {
         KG_FOR_THREADS(tid, NT) {
           const uint32_t c = base + tid;
-          if (c < sh.nclaims && claim_key(S.c_npods[c], S.c_stamp[c], c) <= sh.bestkey) {
+          if (c < sh.nclaims && sh.result != 2 && claim_key(S.c_npods[c], S.c_stamp[c], c) <= sh.bestkey) {
             atomic_add_u32(&sh.st_vis, 1u);
-            ClaimCtx x;
-            uint32_t reason = 0;
-            if (claim_prepare<false>(P, S, sh, c, false, x, &reason)) {
-              uint32_t tv = 0;
-              for (int w = 0; w < P.TW; ++w) tv += popc64(S.c_mask[(size_t)w * P.Cmax + c]);
-              atomic_add_u64(&sh.st_types, tv);
-            }
+            atomic_add_u64(&sh.st_types, S.scratch[(size_t)P.TW * P.Cmax + c]);
+          }
+          // a pod that ends on a fresh claim (or nowhere) visited every in-flight claim
+          if (c < sh.nclaims && sh.result == 2) {
+            atomic_add_u32(&sh.st_vis, 1u);
+            atomic_add_u64(&sh.st_types, S.scratch[(size_t)P.TW * P.Cmax + c]);
           }
         }
       }
@@ -1006,156 +1079,65 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
         if (tid == 0) { S.counters[1] += sh.st_vis; S.counters[2] += sh.st_types; }
       }
     }
-    if (sh.bestkey != ~0ull) {
-      // commit: option mask words in parallel, the scalar state by one thread
+    KG_T(5);
+    if (sh.result != 0) {
+      // ---- commit NodeClaim.Add: the merged row goes back to the claim, the option mask comes from scratch
+      const bool fresh = sh.result == 2;
       KG_FOR_THREADS(tid, NT) {
-        const uint32_t c = (uint32_t)(sh.bestkey & 0xFFFFFu);
-        if (tid >= 64 && tid < 64 + P.TW) {
-          const int w = tid - 64;
-          S.c_mask[(size_t)w * P.Cmax + c] = S.scratch[(size_t)w * P.Cmax + c];
+        const Row& R = sh.result == 3 ? sh.wrow : sh.rows[sh.win_g];
+        const uint32_t c = R.c;
+        for (int a = tid; a < P.Ka; a += NT) S.c_meta[(size_t)a * P.Cmax + c] = R.meta[a];
+        for (int i = tid; i < P.Wa; i += NT) S.c_bits[(size_t)i * P.Cmax + c] = R.bits[i];
+        for (int w = tid; w < P.TW; w += NT) S.c_mask[(size_t)w * P.Cmax + c] = S.scratch[(size_t)w * P.Cmax + c];
+        if (tid >= NT - KG_MAXR) {
+          const int r = tid - (NT - KG_MAXR);
+          if (r < P.R) {
+            S.c_req[(size_t)r * P.Cmax + c] = R.req[r];
+            if (!fresh && sh.preq[r] != 0) S.c_head[(size_t)r * P.Cmax + c] -= sh.preq[r];
+          }
         }
-        if (tid == 0) {
-          ClaimCtx x;
-          uint32_t reason = 0;
-          sh.last_c = c; sh.last_npods = S.c_npods[c]; sh.last_stamp = S.c_stamp[c];
-          claim_prepare<true>(P, S, sh, c, false, x, &reason);
-          claim_commit_tail(P, S, sh, x, c);
+        if (tid == NT / 2) {
+          if (fresh) {
+            S.c_npods[c] = 1; S.c_tmpl[c] = (uint16_t)R.tmpl;
+            sh.last_c = c; sh.last_new = 1;
+            sh.nclaims += 1;
+          } else {
+            sh.last_c = c; sh.last_npods = S.c_npods[c]; sh.last_stamp = S.c_stamp[c]; sh.last_new = 0;
+            S.c_npods[c] += 1;
+          }
           S.c_stamp[c] = ++sh.seq;
+          if (fresh) S.c_hstamp[c] = sh.seq;
           S.pod_kind[sh.pod] = 2;
           S.pod_index[sh.pod] = (int32_t)c;
-          sh.placed = 1;
+          row_record_topology(P, S, sh, R);
         }
       }
       KG_SYNC();
+      if (fresh) {
+        KG_FOR_THREADS(tid, NT) {
+          // headroom of the new claim; subtractMax: charge the worst-case capacity of the remaining options against the limits
+          const uint32_t c = sh.rows[sh.win_g].c;
+          const int t = (int)sh.rows[sh.win_g].tmpl;
+          if (tid < P.R) claim_refresh_head(P, S, c, tid);
+          if (tid >= 64 && tid < 64 + P.R && P.tmpl_has_limits[t]) {
+            const int r = tid - 64;
+            if (P.tmpl_limit_res[(size_t)r * P.NP + t]) {
+              int64_t mx = 0;
+              const int64_t* cp = P.cap + (size_t)P.a_res[r] * P.T;
+              for (int w = 0; w < P.TW; ++w)
+                for (uint64_t mm = S.c_mask[(size_t)w * P.Cmax + c]; mm; mm &= mm - 1) {
+                  const int64_t cv = cp[w * 64 + ctz64(mm)];
+                  if (cv > mx) mx = cv;
+                }
+              S.remaining[(size_t)r * P.NP + t] -= mx;
+            }
+          }
+        }
+        KG_SYNC();
+      }
+      KG_T(6);
       continue;
     }
-    // ---- new NodeClaim from the templates, in weight order
-    for (int t = 0; t < P.NP && !sh.placed; ++t) {
-      const uint32_t c = sh.nclaims;
-      if (c >= (uint32_t)P.Cmax) break;
-      // filterByRemainingResources + NewNodeClaim: materialise claim c from template t
-      KG_FOR_THREADS(tid, NT) {
-        if (tid == 0) { sh.fresh_lim = 0; sh.fresh_any = 0; sh.fresh_ok = 0; }
-      }
-      KG_SYNC();
-      KG_FOR_THREADS(tid, NT) {
-        for (int w = tid; w < P.TW; w += NT) {
-          uint64_t m = ~0ull;
-          if (w == P.TW - 1 && (P.T & 63)) m = (1ull << (P.T & 63)) - 1;
-          if (P.tmpl_has_limits[t]) {
-            for (int r = 0; r < P.R; ++r) {
-              if (!P.tmpl_limit_res[(size_t)r * P.NP + t]) continue;
-              const int idx = thr_lookup_le(P.cthr_val + P.a_cthr_off[r], (int)P.a_cthr_n[r], S.remaining[(size_t)r * P.NP + t]);
-              if (idx < 0) m = 0; else m &= P.cthr_mask[((size_t)P.a_cthr_off[r] + idx) * P.TW + w];
-            }
-          }
-          S.c_mask[(size_t)w * P.Cmax + c] = m;
-          if (m) sh.fresh_lim = 1;
-        }
-        for (int a = tid; a < P.Ka; a += NT) S.c_meta[(size_t)a * P.Cmax + c] = 0;
-        for (int i = tid; i < P.Wa; i += NT) S.c_bits[(size_t)i * P.Cmax + c] = 0;
-        for (int r = tid; r < P.R; r += NT) S.c_req[(size_t)r * P.Cmax + c] = P.tmpl_req[(size_t)r * P.NP + t];
-        if (tid == 0) { S.c_npods[c] = 0; S.c_tmpl[c] = (uint16_t)t; }
-        // hostname placeholder registered for this attempt: hcount rows of slot N+c start at zero
-        for (int gh = tid; gh < P.GH; gh += NT) S.hcount[(size_t)gh * P.H + P.N + c] = 0;
-      }
-      KG_SYNC();
-      KG_FOR_THREADS(tid, NT) {
-        // template requirement entries -> claim state
-        const uint32_t rs = P.tmpl_rs[t];
-        for (uint32_t e = P.rs_off[rs] + tid; e < P.rs_off[rs + 1]; e += NT) {
-          const int a = P.e_slot[e];
-          S.c_meta[(size_t)a * P.Cmax + c] = P.e_meta[e];
-          for (int i = 0; i < P.aw[a]; ++i) S.c_bits[(size_t)(P.aoff[a] + i) * P.Cmax + c] = P.rs_bits[P.e_bits[e] + i];
-        }
-      }
-      KG_SYNC();
-      if (!sh.fresh_lim) {
-        KG_FOR_THREADS(tid, NT) { if (tid == 0) sh.reason |= 16; }  // all available instance types exceed limits
-        KG_SYNC();
-        continue;
-      }
-      // NodeClaim.Add on the fresh claim: one thread per option-mask word
-      KG_FOR_THREADS(tid, NT) {
-        if (tid < P.TW) {
-          ClaimCtx x;
-          uint32_t reason = 0;
-          if (claim_prepare<false>(P, S, sh, c, true, x, &reason)) {
-            const uint64_t m = claim_word(P, S, sh, x, c, tid);
-            S.scratch[(size_t)tid * P.Cmax + c] = m;
-            if (m) sh.fresh_any = 1;
-            if (tid == 0) sh.fresh_ok = 1;
-          } else if (tid == 0) {
-            sh.reason |= reason;
-          }
-        }
-      }
-      KG_SYNC();
-      KG_FOR_THREADS(tid, NT) {
-        if (tid == 0) {
-          if (STATS) {
-            S.counters[3] += 1;
-            if (sh.fresh_ok) {
-              uint32_t tv = 0;
-              for (int w = 0; w < P.TW; ++w) tv += popc64(S.c_mask[(size_t)w * P.Cmax + c]);
-              S.counters[2] += tv;
-            }
-          }
-          bool ok = sh.fresh_ok && sh.fresh_any;
-          if (sh.fresh_ok && !sh.fresh_any) sh.reason |= 8;
-          if (ok && P.tmpl_minv_off[t + 1] > P.tmpl_minv_off[t] && !claim_minvalues_ok(P, S, (uint32_t)t, c)) { ok = false; sh.reason |= 32 | 8; }
-          sh.fresh_ok = ok;
-        }
-      }
-      KG_SYNC();
-      {
-        // every wave reads the verdict before the next attempt's reset may overwrite it
-        const bool ok = sh.fresh_ok != 0;
-        KG_SYNC();
-        if (!ok) continue;
-      }
-      KG_FOR_THREADS(tid, NT) {
-        if (tid >= 64 && tid < 64 + P.TW) {
-          const int w = tid - 64;
-          S.c_mask[(size_t)w * P.Cmax + c] = S.scratch[(size_t)w * P.Cmax + c];
-        }
-        if (tid == 0) {
-          ClaimCtx x;
-          uint32_t reason = 0;
-          claim_prepare<true>(P, S, sh, c, true, x, &reason);
-          claim_commit_tail(P, S, sh, x, c);
-        }
-      }
-      KG_SYNC();
-      KG_FOR_THREADS(tid, NT) {
-        // headroom of the new claim; subtractMax: charge the worst-case capacity of the remaining options against the limits
-        if (tid < P.R) claim_refresh_head(P, S, c, tid);
-        if (tid >= 64 && tid < 64 + P.R && P.tmpl_has_limits[t]) {
-          const int r = tid - 64;
-          if (P.tmpl_limit_res[(size_t)r * P.NP + t]) {
-            int64_t mx = 0;
-            const int64_t* cp = P.cap + (size_t)P.a_res[r] * P.T;
-            for (int w = 0; w < P.TW; ++w)
-              for (uint64_t mm = S.c_mask[(size_t)w * P.Cmax + c]; mm; mm &= mm - 1) {
-                const int64_t cv = cp[w * 64 + ctz64(mm)];
-                if (cv > mx) mx = cv;
-              }
-            S.remaining[(size_t)r * P.NP + t] -= mx;
-          }
-        }
-        if (tid == 0) {
-          S.c_stamp[c] = ++sh.seq;
-          S.c_hstamp[c] = sh.seq;
-          sh.last_c = c; sh.last_new = 1;
-          sh.nclaims += 1;
-          S.pod_kind[sh.pod] = 2;
-          S.pod_index[sh.pod] = (int32_t)c;
-          sh.placed = 1;
-        }
-      }
-      KG_SYNC();
-    }
-    if (sh.placed) continue;
     // ---- Preferences.Relax + Queue.Push
     KG_FOR_THREADS(tid, NT) {
       if (tid == 0) {
@@ -1176,6 +1158,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
       }
     }
     KG_SYNC();
+    KG_T(7);
   }
   KG_FOR_THREADS(tid, NT) {
     if (tid == 0) {
@@ -1184,6 +1167,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     }
   }
   KG_SYNC();
+#undef KG_T
 }
 
 }  // namespace kg

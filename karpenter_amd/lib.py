@@ -50,7 +50,7 @@ class Library:
 
     def set_collect_stats(self, enabled):
         """Reference-visit counters (kg_results.visited_*, algorithmic_bytes): exact but one extra pass per placement."""
-        self._check(self.dll.kg_set_collect_stats(self.ctx, 1 if enabled else 0))
+        self._check(self.dll.kg_set_collect_stats(self.ctx, int(enabled)))
 
     def _check(self, st):
         if st != 0:

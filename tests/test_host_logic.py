@@ -48,3 +48,18 @@ def test_small_batches_sweep(L):
     for seed in (1, 2, 3):
         for n in range(1, 25):
             check(L, Problem(types, wl.mixed_pods(n, seed, zones, fams), [wl.default_nodepool()]))
+
+
+@pytest.mark.parametrize("n,seed", [(40, 3), (700, 5), (1500, 42)])
+def test_prefilter_path_same_placements(L, n, seed):
+    """With the visit counters off the claim scan goes through the conservative prefilter: placements must not change."""
+    zones, types = catalog776()
+    prob = Problem(types, wl.mixed_pods(n, seed, zones, families(types)), [wl.default_nodepool()])
+    ro = prob.run_oracle()
+    L.set_collect_stats(False)
+    try:
+        rg = prob.run_library(L)
+    finally:
+        L.set_collect_stats(True)
+    d = diff_results(ro.decode(), rg.decode())
+    assert d == "", d
