@@ -12,7 +12,7 @@ struct kg_ctx {
   std::string last_error;
   kg_stats stats{};
   bool collect_timers = false;
-  int block_threads = 256;  // workgroup size of k_solve (256 or 1024)
+  int block_threads = 512;  // workgroup size of k_solve (256, 512 or 1024)
   bool collect_stats = true;  // maintain the reference-visit counters (exact; costs an extra pass per placement)
   std::mutex mu;
   uint32_t kHostname, kZone, kCT, kZid, kNodePool, kInstanceType;

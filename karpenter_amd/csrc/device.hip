@@ -5,7 +5,6 @@
 #include <string>
 
 #include "hal.hpp"
-#include "globalize.hpp"
 
 namespace kg {
 
@@ -41,10 +40,25 @@ __global__ void __launch_bounds__(256) k_pod_mask(DevProblem P, PrepassTables X)
 template <int NT>
 __global__ void __launch_bounds__(NT) k_solve(DevProblem Pin, const SimState* sims, const uint32_t* nqueue) {
   __shared__ Shared sh;
-  DevProblem P = Pin;
-  SimState S = sims[blockIdx.x];
-  globalize(P);
-  globalize(S);
+  const DevProblem& P = Pin;
+  const SimState S = sims[blockIdx.x];
+  if (P.stats & 2) {
+    // micro-probes (debug timers only): cost of a bare barrier, of a dependent global load chain, of a flat LDS access
+    __shared__ uint32_t probe[64];
+    unsigned long long t0 = wall_clock64();
+    for (int i = 0; i < 1000; ++i) __syncthreads();
+    unsigned long long t1 = wall_clock64();
+    uint32_t idx = 0;
+    if (threadIdx.x == 0) for (int i = 0; i < 1000; ++i) idx = S.queue[(idx & 3) * 4] & 1;
+    __syncthreads();
+    unsigned long long t2 = wall_clock64();
+    for (int i = 0; i < 1000; ++i) { if (threadIdx.x == 0) probe[i & 63] = (uint32_t)i; __syncthreads(); idx += probe[(i + threadIdx.x) & 63]; __syncthreads(); }
+    unsigned long long t3 = wall_clock64();
+    for (int i = 0; i < 1000; ++i) { if (threadIdx.x == 0) S.scratch[i & 7] = i + idx; __syncthreads(); }
+    unsigned long long t4 = wall_clock64();
+    if (threadIdx.x == 0) { S.counters[26] = t1 - t0; S.counters[27] = t2 - t1; S.counters[28] = t3 - t2 + (idx & 1); S.counters[29] = t4 - t3; }
+    __syncthreads();
+  }
   const unsigned long long c0 = clock64(), w0 = wall_clock64();
   solve_block<NT>(P, S, sh, nqueue[blockIdx.x]);
   if ((P.stats & 2) && threadIdx.x == 0) { S.counters[24] = clock64() - c0; S.counters[25] = wall_clock64() - w0; }
@@ -103,6 +117,7 @@ void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms) {
 void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int block, float* ms) {
   Timer t;
   if (block >= 1024) hipLaunchKernelGGL((k_solve<1024>), dim3(nsims), dim3(1024), 0, 0, P, sims, nqueue);
+  else if (block >= 512) hipLaunchKernelGGL((k_solve<512>), dim3(nsims), dim3(512), 0, 0, P, sims, nqueue);
   else hipLaunchKernelGGL((k_solve<256>), dim3(nsims), dim3(256), 0, 0, P, sims, nqueue);
   ck(hipGetLastError(), "solve launch");
   *ms = t.stop();

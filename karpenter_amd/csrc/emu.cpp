@@ -35,6 +35,7 @@ void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const ui
     static Shared sh;
     std::memset(&sh, 0, sizeof sh);
     if (block >= 1024) solve_block<1024>(P, sims[i], sh, nqueue[i]);
+    else if (block >= 512) solve_block<512>(P, sims[i], sh, nqueue[i]);
     else solve_block<256>(P, sims[i], sh, nqueue[i]);
   }
   *ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -272,7 +272,7 @@ struct Compiled {
   SimState sim{};  // device pointers
   std::vector<uint8_t> state_image;
   size_t o_nreq, o_creq, o_chead, o_chstamp, o_cmask, o_cbits, o_cmeta, o_cnpods, o_ctmpl, o_order, o_remaining, o_gcount, o_gdom, o_gpos, o_hcount, o_hpos, o_queue,
-      o_lastlen, o_lastepoch, o_podvariant, o_podkind, o_podindex, o_podreason, o_scratch, o_header, o_counters, o_nqueue;
+      o_podkind, o_podindex, o_podreason, o_scratch, o_header, o_counters, o_nqueue;
   ~Compiled() {
     hal::dfree(prob_dev.ptr);
     hal::dfree(state_dev.ptr);
@@ -782,6 +782,8 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     }
   }
   tmpl_minv_off[NP] = (uint32_t)minv_slot.size();
+  unsigned long long tmpl_minv_mask = 0;
+  for (int t = 0; t < NP; ++t) if (tmpl_minv_off[t + 1] > tmpl_minv_off[t]) tmpl_minv_mask |= 1ull << t;
   // remaining limits: subtract the capacity of every existing node of the nodepool
   for (int n = 0; n < N; ++n) {
     uint32_t npv = UINT32_MAX;
@@ -988,7 +990,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
                o_ktoff = A.add(ktwv_off), o_ktn = A.add(ktwv_n), o_vrank = A.add(vrank), o_bnd = A.add(bnd_off), o_gtval = A.add(gtval),
                o_ltval = A.add(ltval), o_gtmask = A.add(gtmask), o_ltmask = A.add(ltmask), o_bmo = A.add(bndmask_off), o_rsoff = A.add(rs_off),
                o_eslot = A.add(e_slot), o_emeta = A.add(e_meta), o_ebits = A.add(e_bits), o_rsbits = A.add(rs_bits),
-               o_amask = A.reserve((size_t)std::max(E, 1u) * TW * 8), o_vctx = A.add(vctx), o_podmask = A.reserve((size_t)std::max(NV, 1) * TW * 8), o_pv0 = A.add(pod_variant0), o_preq = A.add(preq),
+               o_amask = A.reserve((size_t)std::max(E, 1u) * TW * 8), o_vctx = A.add(vctx), o_podmask = A.reserve((size_t)std::max(NV, 1) * TW * 8), o_atab = A.reserve(5 * KG_MAXR * 4), o_pv0 = A.add(pod_variant0), o_preq = A.add(preq),
                o_queue0 = A.add(queue0), o_lists = A.add(lists), o_tmplrs = A.add(tmpl_rs), o_tmplreq = A.add(tmpl_req),
                o_thl = A.add(tmpl_has_limits), o_tl0 = A.add(tmpl_limits0), o_tlr = A.add(tmpl_limit_res), o_toltmpl = A.add(tol_tmpl),
                o_minvoff = A.add(tmpl_minv_off), o_minvslot = A.add(minv_slot), o_minvmin = A.add(minv_min), o_navail = A.add(navail),
@@ -1000,9 +1002,11 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   auto dptr = [&](size_t off) { return (uint8_t*)C.prob_dev.ptr + off; };
   auto cptr = [&](size_t off) { return (uint8_t*)CT.dev.ptr + off; };
   DevProblem& D = C.dp;
+  std::vector<uint32_t> atab(5 * KG_MAXR, 0);
   int TWP = 16;
   while (TWP < TW) TWP *= 2;
   if (TWP > 256) throw Unsupported("more than 16384 instance types");
+  D.tmpl_minv_mask = tmpl_minv_mask;
   D.TWP = TWP; D.NV = NV; D.stats = (stats ? 1 : 0) | (ctx->collect_timers ? 2 : 0);
   for (int r = 0; r < R; ++r) {
     const uint32_t g = C.act_res[r];
@@ -1010,8 +1014,10 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     const uint32_t* tn = (const uint32_t*)(CT.image.bytes.data() + CT.o_thr_n);
     const uint32_t* coff = (const uint32_t*)(CT.image.bytes.data() + CT.o_cthr_off);
     const uint32_t* cn = (const uint32_t*)(CT.image.bytes.data() + CT.o_cthr_n);
-    D.a_res[r] = g; D.a_thr_off[r] = toff[g]; D.a_thr_n[r] = tn[g]; D.a_cthr_off[r] = coff[g]; D.a_cthr_n[r] = cn[g];
+    atab[0 * KG_MAXR + r] = toff[g]; atab[1 * KG_MAXR + r] = tn[g]; atab[2 * KG_MAXR + r] = coff[g]; atab[3 * KG_MAXR + r] = cn[g]; atab[4 * KG_MAXR + r] = g;
   }
+  D.atab = (const uint32_t*)dptr(o_atab);
+  hal::h2d(dptr(o_atab), atab.data(), atab.size() * 4);
   D.R = R; D.Ka = Ka; D.Wa = C.Wa; D.T = T; D.TW = TW; D.NP = NP; D.N = N; D.NW = NW; D.P = P; D.S = S; D.G = G; D.GH = GH; D.H = H;
   D.Cmax = Cmax; D.nspec = nspec; D.NL = (int)lists.size();
   D.slot_zone = spec_of_key(ctx->kZone); D.slot_ct = spec_of_key(ctx->kCT); D.slot_zid = spec_of_key(ctx->kZid);
@@ -1055,12 +1061,10 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   C.o_order = SA.reserve((size_t)Cmax * 4);
   C.o_remaining = SA.add(remaining0);
   C.o_gcount = SA.add(gcount0); C.o_gdom = SA.add(gdom0); C.o_gpos = SA.add(gpos0); C.o_hcount = SA.add(hcount0); C.o_hpos = SA.add(hpos0);
-  std::vector<uint32_t> queue(queue0);
-  queue.push_back(0);
+  // Queue ring entries {pod, variant, lastLen epoch, lastLen value}
+  std::vector<uint32_t> queue((size_t)(P + 1) * 4, 0);
+  for (int i = 0; i < P; ++i) { queue[(size_t)i * 4] = queue0[i]; queue[(size_t)i * 4 + 1] = pod_variant0[queue0[i]]; }
   C.o_queue = SA.add(queue);
-  C.o_lastlen = SA.reserve((size_t)std::max(P, 1) * 4);
-  C.o_lastepoch = SA.reserve((size_t)std::max(P, 1) * 4);
-  C.o_podvariant = SA.add(pod_variant0);
   C.o_podkind = SA.reserve((size_t)std::max(P, 1));
   C.o_podindex = SA.reserve((size_t)std::max(P, 1) * 4);
   C.o_podreason = SA.reserve((size_t)std::max(P, 1) * 4);
@@ -1076,8 +1080,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   St.nreq = (int64_t*)sptr(C.o_nreq); St.c_req = (int64_t*)sptr(C.o_creq); St.c_head = (int64_t*)sptr(C.o_chead); St.c_hstamp = (uint32_t*)sptr(C.o_chstamp); St.c_mask = (uint64_t*)sptr(C.o_cmask); St.c_bits = (uint64_t*)sptr(C.o_cbits);
   St.c_meta = (uint32_t*)sptr(C.o_cmeta); St.c_npods = (uint32_t*)sptr(C.o_cnpods); St.c_tmpl = (uint16_t*)sptr(C.o_ctmpl); St.c_stamp = (uint32_t*)sptr(C.o_order);
   St.remaining = (int64_t*)sptr(C.o_remaining); St.gcount = (int32_t*)sptr(C.o_gcount); St.gdom = (uint64_t*)sptr(C.o_gdom); St.gpos = (uint64_t*)sptr(C.o_gpos);
-  St.hcount = (int32_t*)sptr(C.o_hcount); St.hpos = (int32_t*)sptr(C.o_hpos); St.queue = (uint32_t*)sptr(C.o_queue); St.last_len = (uint32_t*)sptr(C.o_lastlen);
-  St.last_epoch = (uint32_t*)sptr(C.o_lastepoch); St.pod_variant = (uint32_t*)sptr(C.o_podvariant); St.pod_kind = (uint8_t*)sptr(C.o_podkind);
+  St.hcount = (int32_t*)sptr(C.o_hcount); St.hpos = (int32_t*)sptr(C.o_hpos); St.queue = (uint32_t*)sptr(C.o_queue); St.pod_kind = (uint8_t*)sptr(C.o_podkind);
   St.pod_index = (int32_t*)sptr(C.o_podindex); St.pod_reason = (uint32_t*)sptr(C.o_podreason); St.scratch = (uint64_t*)sptr(C.o_scratch);
   St.header = (uint32_t*)sptr(C.o_header); St.counters = (uint64_t*)sptr(C.o_counters);
   C.sims_dev.bytes = sizeof(SimState);
@@ -1197,7 +1200,7 @@ int32_t kg_set_collect_stats(kg_ctx* ctx, int32_t enabled) {
   std::lock_guard<std::mutex> lk(ctx->mu);
   ctx->collect_stats = (enabled & 1) != 0;
   ctx->collect_timers = (enabled & 2) != 0;
-  if (enabled & 4) ctx->block_threads = 1024; else ctx->block_threads = 256;  // debugging aid: per-phase ticks of k_solve printed to stderr
+  ctx->block_threads = (enabled & 4) ? 1024 : ((enabled & 8) ? 256 : 512);  // debugging aid: per-phase ticks of k_solve printed to stderr
   return KG_OK;
 }
 
@@ -1340,6 +1343,8 @@ int32_t kg_solve(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, 
     static const char* names[] = {"pop+ctx", "nodes", "prefilter", "sort", "eval", "stats", "commit", "newclaim/relax"};
     for (int i = 0; i < 8; ++i) fprintf(stderr, "[kg timers] %-15s %10.3f ms\n", names[i], counters[8 + i] / 1e5);
     fprintf(stderr, "[kg timers] shader clock %.0f MHz over the launch\n", counters[25] ? counters[24] / (counters[25] / 100.0) : 0.0);
+    fprintf(stderr, "[kg timers] probes (ns each): barrier %.0f, dependent global load %.0f, LDS store+2 barriers+LDS load %.0f, global store+barrier %.0f\n",
+            counters[26] * 10.0 / 1000, counters[27] * 10.0 / 1000, counters[28] * 10.0 / 1000, counters[29] * 10.0 / 1000);
     fprintf(stderr, "[kg timers] survivors %llu rounds %llu false_pos %llu passes %llu\n", (unsigned long long)counters[20],
             (unsigned long long)counters[21], (unsigned long long)counters[22], (unsigned long long)counters[23]);
   }

@@ -16,6 +16,7 @@
 #define KG_DEVICE_ONLY 0
 #define KG_FOR_THREADS(tid, nthreads) for (int tid = 0; tid < (nthreads); ++tid)
 #define KG_SYNC() ((void)0)
+struct alignas(16) uint4 { uint32_t x, y, z, w; };
 namespace kg {
 inline void atomic_min_u32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
 inline void atomic_min_u64(unsigned long long* p, unsigned long long v) { if (v < *p) *p = v; }

@@ -36,9 +36,11 @@ constexpr int KG_MAXLIST = 8;   // topology groups consulted for one pod
 constexpr int KG_EBITS = 32;    // requirement-value words of one pod staged in LDS
 constexpr int KG_THR_LDS = 1024;  // fit-threshold values staged in LDS
 constexpr int KG_MAXSURV = 1024;  // prefilter survivors handled per round
-constexpr int KG_MAXGP = 16;      // NodeClaims evaluated exactly per pass
+constexpr int KG_MAXGP = 32;      // NodeClaims evaluated exactly per pass
 constexpr int KG_ROWW = 64;       // requirement-value words of one claim row
-constexpr int KG_TWLDS = 32;      // option-mask words of the pod's type mask staged in LDS
+constexpr int KG_TWLDS = 16;      // option-mask words (<= 1024 instance types) for the tables staged in LDS
+constexpr int KG_SPV = 8;         // values per special key whose value->types rows are staged in LDS
+constexpr int KG_OFFROWS = 16;    // (zone, capacity-type) offering rows staged in LDS
 constexpr uint32_t KG_NOIDX = 0xFFFFFFFFu;
 
 // requirement meta word
@@ -113,8 +115,10 @@ struct DevProblem {
   int slot_zone, slot_ct, slot_zid;  // special indices (sp) or -1
   uint32_t well_known_slots;         // bit per active slot
   uint32_t stats;                    // 1 = maintain the reference-visit counters (exact, slower)
+  unsigned long long tmpl_minv_mask;  // bit per template: its requirements carry minValues
   // active resources -> rows of the catalog's per-resource tables
-  uint32_t a_thr_off[KG_MAXR], a_thr_n[KG_MAXR], a_cthr_off[KG_MAXR], a_cthr_n[KG_MAXR], a_res[KG_MAXR];
+  // (kept behind a pointer: an array inside this by-value struct would push the whole struct into scratch memory)
+  const uint32_t* atab;  // [5][KG_MAXR]: thr_off, thr_n, cthr_off, cthr_n, global resource id
   // active keys
   const uint16_t* aoff;   // [Ka] word offset of the slot in a requirement row
   const uint16_t* aw;     // [Ka] words
@@ -195,10 +199,7 @@ struct SimState {
   uint64_t* gpos;     // [G] domains with count > 0
   int32_t* hcount;    // [GH][H]
   int32_t* hpos;      // [GH] hosts with count > 0
-  uint32_t* queue;    // [P+1] ring
-  uint32_t* last_len; // [P]
-  uint32_t* last_epoch; // [P]
-  uint32_t* pod_variant;// [P]
+  uint32_t* queue;    // [P+1][4] ring of {pod, variant, lastLen epoch, lastLen value}: one 16-byte load per Queue.Pop
   uint8_t* pod_kind;  // [P]
   int32_t* pod_index; // [P]
   uint32_t* pod_reason; // [P]
@@ -211,6 +212,7 @@ struct SimState {
 // merged into it in place (NodeClaim.Add steps 3-5), and the winner's copy is what the commit writes back.
 struct Row {
   uint32_t c, tmpl, ok, reason, feas, tv;
+  uint32_t npods, stamp;
   uint32_t ent_changed, ent_dne_ok, sp_changed, thr_use, has_topo, pad_;
   int32_t thr_idx[KG_MAXR];
   int64_t req[KG_MAXR];            // claim requests; after the merge: requests including the pod
@@ -228,16 +230,22 @@ struct Shared {
   int64_t preq[KG_MAXR];
   VariantCtx vc;
   uint64_t podmask[KG_TWLDS];       // the pod variant's own type mask (prefilter)
+  uint64_t eam[KG_MAXE][KG_TWLDS];  // e_amask rows of the pod's requirement entries
+  uint32_t cur_epoch, cur_len, tw_lds, off_lds, stw_lds;
+  uint64_t offm[KG_OFFROWS][KG_TWLDS];          // offering masks [zone * n_ct + ct]
+  uint64_t stw[KG_MAXSPEC][KG_SPV][KG_TWLDS];   // value->types rows of the special keys
   // small problem tables
   uint16_t aoff[KG_MAXKA], aw[KG_MAXKA];
   int8_t slot2spec[KG_MAXKA];
   uint8_t spec_slot[KG_MAXSPEC + 2];
   uint32_t thr_base[KG_MAXR];
+  uint32_t a_thr_off[KG_MAXR], a_thr_n[KG_MAXR], a_cthr_off[KG_MAXR], a_cthr_n[KG_MAXR], a_res[KG_MAXR];
   int64_t thr_val[KG_THR_LDS];
   // prefilter survivors of the current round
   uint32_t surv[KG_MAXSURV];             // claim ids, in arrival order
   unsigned long long skey[KG_MAXSURV];   // their scan-order keys
   uint32_t sorted[KG_MAXSURV];           // claim ids in scan order
+  uint32_t srank[KG_MAXSURV];            // rank accumulators
   Row rows[KG_MAXGP];                    // evaluation groups of the current pass
   Row wrow;                              // the best NodeClaim so far when the scan needs more than one round
 };
@@ -467,8 +475,8 @@ KG_HD void row_merge_resource(const DevProblem& P, const Shared& sh, Row& R, int
   const int64_t nr = R.req[r] + add;
   R.req[r] = nr;
   if (nr > 0) {
-    const int64_t* tv = sh.thr_lds ? sh.thr_val + sh.thr_base[r] : P.thr_val + P.a_thr_off[r];
-    R.thr_idx[r] = thr_lookup_ge(tv, (int)P.a_thr_n[r], nr);
+    const int64_t* tv = sh.thr_lds ? sh.thr_val + sh.thr_base[r] : P.thr_val + sh.a_thr_off[r];
+    R.thr_idx[r] = thr_lookup_ge(tv, (int)sh.a_thr_n[r], nr);
     atomic_or_u32(&R.thr_use, 1u << r);
   }
 }
@@ -525,7 +533,7 @@ KG_HD uint64_t row_word(const DevProblem& P, const SimState& S, const Shared& sh
     if (!((R.ent_changed >> j) & 1)) continue;
     const PodEntry pe = sh.vc.ent[j];
     if (pe.spec >= 0) continue;
-    uint64_t f = P.e_amask[(size_t)pe.e * P.TW + w];
+    uint64_t f = sh.tw_lds ? sh.eam[j][w] : P.e_amask[(size_t)pe.e * P.TW + w];
     if ((R.ent_dne_ok >> j) & 1) f |= P.kU[(size_t)pe.slot * P.TW + w];
     m &= f;
   }
@@ -561,10 +569,14 @@ KG_HD uint64_t row_word(const DevProblem& P, const SimState& S, const Shared& sh
     if (changed && present) {
       uint64_t f = P.kN[(size_t)a * P.TW + w];
       if (op_neg(opclass(sp.meta & RM_COMPL, sp.word != 0))) f |= P.kU[(size_t)a * P.TW + w];
-      const int nv = P.ktwv_n[a];
-      for (uint64_t mm = hm; mm; mm &= mm - 1) {
-        const int d = ctz64(mm);
-        if (d < nv) f |= P.twv[((size_t)P.ktwv_off[a] + d) * P.TW + w];
+      if (sh.stw_lds) {
+        for (uint64_t mm = hm & ((1ull << KG_SPV) - 1); mm; mm &= mm - 1) f |= sh.stw[i][ctz64(mm)][w];
+      } else {
+        const int nv = P.ktwv_n[a];
+        for (uint64_t mm = hm; mm; mm &= mm - 1) {
+          const int d = ctz64(mm);
+          if (d < nv) f |= P.twv[((size_t)P.ktwv_off[a] + d) * P.TW + w];
+        }
       }
       m &= f;
     }
@@ -581,10 +593,16 @@ KG_HD uint64_t row_word(const DevProblem& P, const SimState& S, const Shared& sh
     }
   }
   // fits
-  for (int r = 0; r < P.R; ++r) {
-    if (!((R.thr_use >> r) & 1)) continue;
-    if (R.thr_idx[r] >= (int)P.a_thr_n[r]) m = 0;
-    else m &= P.thr_mask[((size_t)P.a_thr_off[r] + R.thr_idx[r]) * P.TW + w];
+  {
+    uint64_t tm[KG_MAXR];
+#pragma unroll
+    for (int r = 0; r < KG_MAXR; ++r) {
+      const bool use = r < P.R && ((R.thr_use >> r) & 1);
+      const bool none = use && R.thr_idx[r] >= (int)sh.a_thr_n[r];
+      tm[r] = !use ? ~0ull : (none ? 0ull : P.thr_mask[((size_t)sh.a_thr_off[r] + (none ? 0 : R.thr_idx[r])) * P.TW + w]);
+    }
+#pragma unroll
+    for (int r = 0; r < KG_MAXR; ++r) m &= tm[r];
   }
   if (fresh) m &= P.valid_types[w];
   // hasOffering
@@ -593,7 +611,7 @@ KG_HD uint64_t row_word(const DevProblem& P, const SimState& S, const Shared& sh
     for (int z = 0; z < P.n_zone_vals; ++z) {
       if (!((zmask >> z) & 1)) continue;
       for (int ct = 0; ct < P.n_ct_vals; ++ct)
-        if ((ctmask >> ct) & 1) f |= P.offmask[((size_t)z * 4 + ct) * P.TW + w];
+        if ((ctmask >> ct) & 1) f |= sh.off_lds ? sh.offm[z * P.n_ct_vals + ct][w] : P.offmask[((size_t)z * 4 + ct) * P.TW + w];
     }
     m &= f;
   }
@@ -674,9 +692,9 @@ KG_HD void row_record_topology(const DevProblem& P, const SimState& S, const Sha
 
 // max allocatable of active resource r over the option mask of claim c, minus its requests: the prefilter's headroom.
 // Computed when a claim is created and when the prefilter let an infeasible claim through.
-KG_HD void claim_refresh_head(const DevProblem& P, const SimState& S, uint32_t c, int r) {
+KG_HD void claim_refresh_head(const DevProblem& P, const SimState& S, const Shared& sh, uint32_t c, int r) {
   int64_t mx = 0;
-  const int64_t* al = P.alloc + (size_t)P.a_res[r] * P.T;
+  const int64_t* al = P.alloc + (size_t)sh.a_res[r] * P.T;
   for (int w = 0; w < P.TW; ++w)
     for (uint64_t mm = S.c_mask[(size_t)w * P.Cmax + c]; mm; mm &= mm - 1) {
       const int64_t v = al[w * 64 + ctz64(mm)];
@@ -746,20 +764,48 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
   const uint32_t GP = (NT / TWP) < (uint32_t)KG_MAXGP ? (NT / TWP) : (uint32_t)KG_MAXGP;  // survivors evaluated per pass
   // ---- stage the small problem tables in LDS
   KG_FOR_THREADS(tid, NT) {
+    if (tid < KG_MAXR) {
+      sh.a_thr_off[tid] = P.atab[0 * KG_MAXR + tid]; sh.a_thr_n[tid] = P.atab[1 * KG_MAXR + tid]; sh.a_cthr_off[tid] = P.atab[2 * KG_MAXR + tid];
+      sh.a_cthr_n[tid] = P.atab[3 * KG_MAXR + tid]; sh.a_res[tid] = P.atab[4 * KG_MAXR + tid];
+    }
+  }
+  KG_SYNC();
+  KG_FOR_THREADS(tid, NT) {
     if (tid == 0) {
       sh.qhead = 0; sh.qlen = n_queue; sh.epoch = 1; sh.nclaims = S.header[0]; sh.done = 0; sh.seq = 0; sh.last_c = KG_NOIDX; sh.last_new = 0;
       uint32_t tot = 0;
-      for (int r = 0; r < P.R; ++r) { sh.thr_base[r] = tot; tot += P.a_thr_n[r]; }
+      for (int r = 0; r < P.R; ++r) { sh.thr_base[r] = tot; tot += sh.a_thr_n[r]; }
       sh.thr_lds = tot <= (uint32_t)KG_THR_LDS;
     }
     for (int a = tid; a < P.Ka; a += NT) { sh.aoff[a] = P.aoff[a]; sh.aw[a] = P.aw[a]; sh.slot2spec[a] = P.slot2spec[a]; }
     for (int i = tid; i < P.nspec; i += NT) sh.spec_slot[i] = P.spec_slot[i];
+    if (tid == 0) {
+      sh.tw_lds = P.TW <= KG_TWLDS;
+      sh.off_lds = P.TW <= KG_TWLDS && P.n_zone_vals * P.n_ct_vals <= KG_OFFROWS;
+      bool ok = P.TW <= KG_TWLDS;
+      for (int i = 0; i < P.nspec; ++i) ok = ok && P.ktwv_n[P.spec_slot[i]] <= KG_SPV;
+      sh.stw_lds = ok;
+    }
+  }
+  KG_SYNC();
+  KG_FOR_THREADS(tid, NT) {
+    if (sh.off_lds)
+      for (int i = tid; i < P.n_zone_vals * P.n_ct_vals * P.TW; i += NT) {
+        const int row = i / P.TW, w = i % P.TW;
+        sh.offm[row][w] = P.offmask[((size_t)(row / P.n_ct_vals) * 4 + (row % P.n_ct_vals)) * P.TW + w];
+      }
+    if (sh.stw_lds)
+      for (int i = tid; i < P.nspec * KG_SPV * P.TW; i += NT) {
+        const int sp = i / (KG_SPV * P.TW), d = (i / P.TW) % KG_SPV, w = i % P.TW;
+        const int a = P.spec_slot[sp];
+        sh.stw[sp][d][w] = d < (int)P.ktwv_n[a] ? P.twv[((size_t)P.ktwv_off[a] + d) * P.TW + w] : 0;
+      }
   }
   KG_SYNC();
   if (sh.thr_lds) {
     KG_FOR_THREADS(tid, NT) {
       for (int r = 0; r < P.R; ++r)
-        for (uint32_t i = tid; i < P.a_thr_n[r]; i += NT) sh.thr_val[sh.thr_base[r] + i] = P.thr_val[P.a_thr_off[r] + i];
+        for (uint32_t i = tid; i < sh.a_thr_n[r]; i += NT) sh.thr_val[sh.thr_base[r] + i] = P.thr_val[sh.a_thr_off[r] + i];
     }
     KG_SYNC();
   }
@@ -770,13 +816,13 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
       if (tid == 0) {
         if (sh.qlen == 0) sh.done = 1;
         else {
-          const uint32_t pod = S.queue[sh.qhead % QCAP];
-          if (S.last_epoch[pod] == sh.epoch && S.last_len[pod] == sh.qlen) sh.done = 1;
+          const uint4 qe = ((const uint4*)S.queue)[sh.qhead % QCAP];
+          if (qe.z == sh.epoch && qe.w == sh.qlen) sh.done = 1;
           else {
-            sh.pod = pod;
+            sh.pod = qe.x;
             sh.qhead = (sh.qhead + 1) % QCAP;
             sh.qlen -= 1;
-            sh.variant = S.pod_variant[pod];
+            sh.variant = qe.y;
             sh.best = KG_NOIDX;
             sh.reason = 0;
           }
@@ -795,6 +841,12 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
         sh.preq[r] = r < P.R ? P.preq[(size_t)sh.pod * P.R + r] : 0;
       }
       if (tid >= NT / 2 && tid < NT / 2 + P.TW && P.TW <= KG_TWLDS) sh.podmask[tid - NT / 2] = P.podmask[(size_t)sh.variant * P.TW + (tid - NT / 2)];
+      if (tid >= 96 && tid < 96 + KG_MAXE * KG_TWLDS && P.TW <= KG_TWLDS) {
+        // e_amask rows of the pod's requirement entries (entry ids straight from the global record: same round trip)
+        const uint32_t j = (uint32_t)(tid - 96) / KG_TWLDS, w = (uint32_t)(tid - 96) % KG_TWLDS;
+        const VariantCtx* gv = P.vctx + sh.variant;
+        if (j < gv->ne && w < (uint32_t)P.TW) sh.eam[j][w] = P.e_amask[(size_t)gv->ent[j].e * P.TW + w];
+      }
       // (sh.placed & co are reset here, a barrier after the last uniform read of them, not in Queue.Pop)
       // The reference sorts newNodeClaims at the start of the claim stage of every add(); what happens after (one pod
       // added to a claim, or one claim appended) is not re-sorted, and Results returns the slice as it stands.
@@ -853,22 +905,27 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
             const uint32_t c = round_end + tid;
             if (c < sh.nclaims) {
               bool ok = true;
+              const uint32_t np_ = S.c_npods[c], st_ = S.c_stamp[c];
               if (!STATS) {
-                ok = ((P.tol_tmpl[sh.vc.v.tolset] >> S.c_tmpl[c]) & 1) && sh.vc.v.host_claim_ok;
-                for (int r = 0; ok && r < P.R; ++r) ok = sh.preq[r] == 0 || S.c_head[(size_t)r * P.Cmax + c] >= sh.preq[r];
-                if (ok) {
-                  uint64_t any = 0;
-                  if (P.TW <= KG_TWLDS) {
-                    for (int w = 0; w < P.TW; ++w) any |= S.c_mask[(size_t)w * P.Cmax + c] & sh.podmask[w];
-                  } else {
-                    const uint64_t* pm = P.podmask + (size_t)sh.variant * P.TW;
-                    for (int w = 0; w < P.TW; ++w) any |= S.c_mask[(size_t)w * P.Cmax + c] & pm[w];
-                  }
-                  ok = any != 0;
+                // every load below is independent: one round trip to memory for the whole test
+                const uint32_t tm = S.c_tmpl[c];
+                int64_t hd[KG_MAXR];
+#pragma unroll
+                for (int r = 0; r < KG_MAXR; ++r) hd[r] = (r < P.R && sh.preq[r] != 0) ? S.c_head[(size_t)r * P.Cmax + c] : 0;
+                uint64_t any = 0;
+                if (P.TW <= KG_TWLDS) {
+#pragma unroll
+                  for (int w = 0; w < KG_TWLDS; ++w) if (w < P.TW) any |= S.c_mask[(size_t)w * P.Cmax + c] & sh.podmask[w];
+                } else {
+                  const uint64_t* pm = P.podmask + (size_t)sh.variant * P.TW;
+                  for (int w = 0; w < P.TW; ++w) any |= S.c_mask[(size_t)w * P.Cmax + c] & pm[w];
                 }
+                ok = ((P.tol_tmpl[sh.vc.v.tolset] >> tm) & 1) && sh.vc.v.host_claim_ok && any != 0;
+#pragma unroll
+                for (int r = 0; r < KG_MAXR; ++r) ok = ok && (r >= P.R || sh.preq[r] == 0 || hd[r] >= sh.preq[r]);
               }
               if (ok) {
-                const unsigned long long key = claim_key(S.c_npods[c], S.c_stamp[c], c);
+                const unsigned long long key = claim_key(np_, st_, c);
                 if (key < sh.bestkey) {
                   const uint32_t i = atomic_inc_u32(&sh.nsurv);
                   sh.surv[i] = c;
@@ -882,15 +939,39 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
         KG_T(2);
         // order the survivors by key (rank by counting; keys are unique)
         ns = sh.nsurv;
+        // (PARTS threads share one survivor's count when the list is short)
+        uint32_t nsp = 1;
+        while (nsp < ns) nsp <<= 1;
+        const uint32_t PARTS = nsp >= (uint32_t)NT ? 1u : (uint32_t)NT / nsp;
+        if (PARTS > 1) {
+          KG_FOR_THREADS(tid, NT) { if ((uint32_t)tid < ns) sh.srank[tid] = 0; }
+          KG_SYNC();
+        }
         KG_FOR_THREADS(tid, NT) {
-          for (uint32_t i = tid; i < ns; i += NT) {
-            const unsigned long long k = sh.skey[i];
-            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-            uint32_t j = 0;
-            for (; j + 4 <= ns; j += 4) { r0 += sh.skey[j] < k; r1 += sh.skey[j + 1] < k; r2 += sh.skey[j + 2] < k; r3 += sh.skey[j + 3] < k; }
-            for (; j < ns; ++j) r0 += sh.skey[j] < k;
-            sh.sorted[r0 + r1 + r2 + r3] = sh.surv[i];
+          if (PARTS > 1) {
+            const uint32_t i = (uint32_t)tid / PARTS, part = (uint32_t)tid % PARTS;
+            if (i < ns) {
+              const unsigned long long k = sh.skey[i];
+              const uint32_t per = (ns + PARTS - 1) / PARTS;
+              const uint32_t j0 = part * per, j1 = j0 + per < ns ? j0 + per : ns;
+              uint32_t r0 = 0;
+              for (uint32_t j = j0; j < j1; ++j) r0 += sh.skey[j] < k;
+              if (r0) atomic_add_u32(&sh.srank[i], r0);
+            }
+          } else {
+            for (uint32_t i = tid; i < ns; i += NT) {
+              const unsigned long long k = sh.skey[i];
+              uint32_t r0 = 0;
+              for (uint32_t j = 0; j < ns; ++j) r0 += sh.skey[j] < k;
+              sh.sorted[r0] = sh.surv[i];
+            }
           }
+        }
+        if (PARTS > 1) {
+          KG_SYNC();
+          KG_FOR_THREADS(tid, NT) { if ((uint32_t)tid < ns) sh.sorted[sh.srank[tid]] = sh.surv[tid]; }
+        }
+        KG_FOR_THREADS(tid, NT) {
           if (tid == 0) { sh.scan_base = round_end < sh.nclaims ? round_end : sh.nclaims; sh.pass_lo = 0; sh.winner = KG_NOIDX; }
         }
         KG_SYNC();
@@ -924,8 +1005,8 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
             if (P.tmpl_has_limits[t]) {
               for (int r = 0; r < P.R; ++r) {
                 if (!P.tmpl_limit_res[(size_t)r * P.NP + t]) continue;
-                const int idx = thr_lookup_le(P.cthr_val + P.a_cthr_off[r], (int)P.a_cthr_n[r], S.remaining[(size_t)r * P.NP + t]);
-                if (idx < 0) m = 0; else m &= P.cthr_mask[((size_t)P.a_cthr_off[r] + idx) * P.TW + w];
+                const int idx = thr_lookup_le(P.cthr_val + sh.a_cthr_off[r], (int)sh.a_cthr_n[r], S.remaining[(size_t)r * P.NP + t]);
+                if (idx < 0) m = 0; else m &= P.cthr_mask[((size_t)sh.a_cthr_off[r] + idx) * P.TW + w];
               }
             }
             S.c_mask[(size_t)w * P.Cmax + c] = m;
@@ -952,11 +1033,26 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
             if (gi < GP && lo + gi < ns) {
               Row& R = sh.rows[gi];
               const uint32_t c = sh.sorted[lo + gi];
-              for (int a = (int)w; a < P.Ka; a += (int)TWP) R.meta[a] = S.c_meta[(size_t)a * P.Cmax + c];
-              for (int i = (int)w; i < P.Wa; i += (int)TWP) R.bits[i] = S.c_bits[(size_t)i * P.Cmax + c];
-              if (w < KG_MAXR) R.req[w] = w < (uint32_t)P.R ? S.c_req[(size_t)w * P.Cmax + c] : 0;
+              if (TWP == 16) {
+                // straight-line, independent loads (Ka <= 32 metas, Wa <= 64 words, R <= 8 requests): one round trip
+                const uint32_t m0 = w < (uint32_t)P.Ka ? S.c_meta[(size_t)w * P.Cmax + c] : 0;
+                const uint32_t m1 = w + 16 < (uint32_t)P.Ka ? S.c_meta[(size_t)(w + 16) * P.Cmax + c] : 0;
+                uint64_t b[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) b[k] = w + 16 * k < (uint32_t)P.Wa ? S.c_bits[(size_t)(w + 16 * k) * P.Cmax + c] : 0;
+                const int64_t rq = w < (uint32_t)P.R ? S.c_req[(size_t)w * P.Cmax + c] : 0;
+                R.meta[w] = m0; R.meta[w + 16] = m1;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) R.bits[w + 16 * k] = b[k];
+                if (w < KG_MAXR) R.req[w] = rq;
+              } else {
+                for (int a = (int)w; a < P.Ka; a += (int)TWP) R.meta[a] = S.c_meta[(size_t)a * P.Cmax + c];
+                for (int i = (int)w; i < P.Wa; i += (int)TWP) R.bits[i] = S.c_bits[(size_t)i * P.Cmax + c];
+                if (w < KG_MAXR) R.req[w] = w < (uint32_t)P.R ? S.c_req[(size_t)w * P.Cmax + c] : 0;
+              }
               if (w == TWP - 1) {
                 const uint32_t tm = S.c_tmpl[c];
+                R.npods = S.c_npods[c]; R.stamp = S.c_stamp[c];
                 R.c = c; R.tmpl = tm; R.reason = 0; R.feas = 0; R.tv = 0; R.ent_changed = 0; R.ent_dne_ok = 0; R.sp_changed = 0; R.thr_use = 0;
                 R.ok = ((P.tol_tmpl[sh.vc.v.tolset] >> tm) & 1) && sh.vc.v.host_claim_ok;
               }
@@ -998,7 +1094,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
             for (uint32_t gi = 0; gi < GP && lo + gi < ns; ++gi) {
               Row& R = sh.rows[gi];
               bool ok = R.ok && R.feas;
-              if (ok && P.tmpl_minv_off[R.tmpl + 1] > P.tmpl_minv_off[R.tmpl] && !claim_minvalues_ok(P, S, R.tmpl, R.c)) { ok = false; R.reason |= 32; }
+              if (ok && ((P.tmpl_minv_mask >> R.tmpl) & 1) && !claim_minvalues_ok(P, S, R.tmpl, R.c)) { ok = false; R.reason |= 32; }
               if (R.ok && !ok) R.reason |= 8;
               if (STATS) {
                 if (!fresh) S.scratch[(size_t)P.TW * P.Cmax + R.c] = R.ok ? R.tv : 0;
@@ -1019,7 +1115,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
           KG_FOR_THREADS(tid, NT) {
             const uint32_t gi = (uint32_t)tid / KG_MAXR;
             const int r = tid % KG_MAXR;
-            if (gi < GP && lo + gi < ns && r < P.R && sh.rows[gi].feas == 2) claim_refresh_head(P, S, sh.rows[gi].c, r);
+            if (gi < GP && lo + gi < ns && r < P.R && sh.rows[gi].feas == 2) claim_refresh_head(P, S, sh, sh.rows[gi].c, r);
           }
           KG_SYNC();
         }
@@ -1040,8 +1136,8 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
         if (tid == 0) {
           if (!fresh) {
             if (sh.winner != KG_NOIDX) {
-              const uint32_t c = sh.winner;
-              sh.bestkey = claim_key(S.c_npods[c], S.c_stamp[c], c);
+              const Row& W = sh.rows[sh.win_g];
+              sh.bestkey = claim_key(W.npods, W.stamp, W.c);
               sh.result = more_rounds ? 3 : 1;  // 3: the row was parked in wrow
             }
             if (!more_rounds) sh.stage = sh.bestkey != ~0ull ? 2 : ((sh.nclaims < (uint32_t)P.Cmax && P.NP > 0) ? 1 : 2);
@@ -1102,8 +1198,8 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
             sh.last_c = c; sh.last_new = 1;
             sh.nclaims += 1;
           } else {
-            sh.last_c = c; sh.last_npods = S.c_npods[c]; sh.last_stamp = S.c_stamp[c]; sh.last_new = 0;
-            S.c_npods[c] += 1;
+            sh.last_c = c; sh.last_npods = R.npods; sh.last_stamp = R.stamp; sh.last_new = 0;
+            S.c_npods[c] = R.npods + 1;
           }
           S.c_stamp[c] = ++sh.seq;
           if (fresh) S.c_hstamp[c] = sh.seq;
@@ -1118,12 +1214,12 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
           // headroom of the new claim; subtractMax: charge the worst-case capacity of the remaining options against the limits
           const uint32_t c = sh.rows[sh.win_g].c;
           const int t = (int)sh.rows[sh.win_g].tmpl;
-          if (tid < P.R) claim_refresh_head(P, S, c, tid);
+          if (tid < P.R) claim_refresh_head(P, S, sh, c, tid);
           if (tid >= 64 && tid < 64 + P.R && P.tmpl_has_limits[t]) {
             const int r = tid - 64;
             if (P.tmpl_limit_res[(size_t)r * P.NP + t]) {
               int64_t mx = 0;
-              const int64_t* cp = P.cap + (size_t)P.a_res[r] * P.T;
+              const int64_t* cp = P.cap + (size_t)sh.a_res[r] * P.T;
               for (int w = 0; w < P.TW; ++w)
                 for (uint64_t mm = S.c_mask[(size_t)w * P.Cmax + c]; mm; mm &= mm - 1) {
                   const int64_t cv = cp[w * 64 + ctz64(mm)];
@@ -1145,16 +1241,19 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
         S.pod_kind[pod] = 0;
         S.pod_index[pod] = -1;
         S.pod_reason[pod] = sh.reason ? sh.reason : 8;
-        S.queue[(sh.qhead + sh.qlen) % QCAP] = pod;
+        uint4 qe;
+        qe.x = pod;
         sh.qlen += 1;
         if (sh.vc.v.next >= 0) {
-          S.pod_variant[pod] = (uint32_t)sh.vc.v.next;
+          qe.y = (uint32_t)sh.vc.v.next;
+          qe.z = 0; qe.w = 0;
           sh.epoch += 1;  // lastLen = {} on a relaxed push
           S.header[1] += 1;
         } else {
-          S.last_len[pod] = sh.qlen;
-          S.last_epoch[pod] = sh.epoch;
+          qe.y = sh.variant;
+          qe.z = sh.epoch; qe.w = sh.qlen;  // lastLen[pod] = len(queue) after the push
         }
+        ((uint4*)S.queue)[(sh.qhead + sh.qlen - 1) % QCAP] = qe;
       }
     }
     KG_SYNC();
