@@ -65,3 +65,35 @@ class Problem:
                 L.dll.kg_cluster_free(hcl)
             if own:
                 L.dll.kg_catalog_free(hcat)
+
+
+def c5_nodepools():
+    """C5: four weighted NodePools, the two heaviest with cpu limits (scaled)."""
+    return [wl.default_nodepool("np-a", weight=100, limits={"cpu": 200000}), wl.default_nodepool("np-b", weight=50, limits={"cpu": 1000000}),
+            wl.default_nodepool("np-c", weight=10), wl.default_nodepool("np-d", weight=0)]
+
+
+def scenario(name):
+    """Named parity scenarios shared by the emulation (CPU) and GPU test files."""
+    zones, types = catalog776()
+    if name == "c3_small":
+        return Problem(types, wl.spread_pods(6, 20, 7), [wl.default_nodepool()])
+    if name == "c3_mid":
+        return Problem(types, wl.spread_pods(20, 50, 7), [wl.default_nodepool()])
+    if name == "c3_large":
+        return Problem(types, wl.spread_pods(200, 25, 7), [wl.default_nodepool()])
+    if name == "existing_small":
+        nodes, bound = wl.existing_cluster(60, 11, types, zones)
+        return Problem(types, wl.mixed_pods(200, 3, zones, families(types)), [wl.default_nodepool()], nodes=nodes, bound=bound)
+    if name == "existing_mid":
+        nodes, bound = wl.existing_cluster(300, 12, types, zones)
+        return Problem(types, wl.mixed_pods(1000, 4, zones, families(types)), [wl.default_nodepool()], nodes=nodes, bound=bound)
+    if name == "existing_large":
+        nodes, bound = wl.existing_cluster(2000, 12, types, zones)
+        return Problem(types, wl.mixed_pods(4000, 4, zones, families(types)), [wl.default_nodepool()], nodes=nodes, bound=bound)
+    if name in ("c5_small", "c5_mid"):
+        z6, t6 = catalog776(6)
+        n_nodes, n_pods = (100, 1500) if name == "c5_small" else (600, 12000)
+        nodes, bound = wl.existing_cluster(n_nodes, 13, t6, z6, nodepool="np-a")
+        return Problem(t6, wl.mixed_pods(n_pods, 99, z6, families(t6)), c5_nodepools(), nodes=nodes, bound=bound)
+    raise KeyError(name)

@@ -4,7 +4,7 @@ requests, visit counters)."""
 import pytest
 
 from karpenter_amd import lib, workloads as wl
-from tests.helpers import Problem, catalog776, diff_results, families
+from tests.helpers import Problem, catalog776, diff_results, families, scenario
 
 pytestmark = pytest.mark.gpu
 
@@ -63,3 +63,9 @@ def test_c2_full(L):
     zones, types = catalog776()
     ro, rg = check(L, Problem(types, wl.mixed_pods(10000, 42, zones, families(types)), [wl.default_nodepool()]))
     print("C2 full: oracle %.1f ms, device %.2f ms" % (ro.res.device_ms, rg.res.device_ms))
+
+
+@pytest.mark.parametrize("name", ["c3_small", "c3_mid", "c3_large", "existing_small", "existing_mid", "existing_large", "c5_small", "c5_mid"])
+def test_scenarios(L, name):
+    """C3 topology spread / anti-affinity, existing nodes, C5 weighted NodePools with limits -- bit for bit vs the oracle."""
+    check(L, scenario(name))

@@ -63,3 +63,13 @@ def test_prefilter_path_same_placements(L, n, seed):
         L.set_collect_stats(True)
     d = diff_results(ro.decode(), rg.decode())
     assert d == "", d
+
+
+@pytest.mark.parametrize("name", ["c3_small", "c3_mid", "existing_small", "existing_mid", "c5_small"])
+def test_scenarios(L, name):
+    """C3 (zone + hostname spread, hostname anti-affinity), existing nodes first (ExistingNode.Add), C5 (weighted
+    NodePools with limits, 6 zones, existing nodes charged against the limits)."""
+    from tests.helpers import scenario
+    ro, _ = check(L, scenario(name))
+    if name.startswith("existing") or name.startswith("c5"):
+        assert any(k == 1 for k, _ in ro.decode()["pods"])
