@@ -332,11 +332,13 @@ typedef struct {
 
 /* per-candidate record (also the fixed-size record gathered across GPUs) */
 typedef struct {
-  int32_t candidate;         /* index in candidates[] (single) or prefix length-1 (multi) */
-  int32_t decision;          /* before first-wins selection */
+  int32_t candidate;         /* index in candidates[] (single) or `mid` = prefix length-1 (multi) */
+  int32_t decision;          /* computeConsolidation's verdict for this unit, before first-wins / binary-search selection */
   uint32_t nodepool, n_types;
-  double candidate_price;
-  uint64_t type_mask[13];    /* catalog types of the replacement (<= 832 types) after price filters */
+  double candidate_price;    /* getCandidatePrices: sum of the cheapest offering compatible with each candidate's labels */
+  uint64_t type_mask[13];    /* catalog types of the replacement (<= 832 types) after the price filters */
+  uint64_t zone_mask, ct_mask; /* replacement requirements on zone / capacity type as the library's value-id masks (opaque;
+                                  kg_consolidate_select uses them to price-order the options) */
   uint8_t spot_only; uint8_t pad[7];
 } kg_candidate_record;
 
@@ -412,7 +414,7 @@ int32_t kg_consolidate_multi(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t 
                              const kg_candidates_desc* cands, kg_candidate_record* records, uint32_t cap_records,
                              uint32_t* n_records, double* device_ms);
 /* first-wins (single) / binary-search replay (multi) over records gathered from all shards. */
-int32_t kg_consolidate_select(int32_t multi, const kg_candidate_record* records, uint32_t n_records,
+int32_t kg_consolidate_select(kg_ctx* ctx, kg_catalog* catalog, int32_t multi, const kg_candidate_record* records, uint32_t n_records,
                               uint32_t n_candidates, kg_decision* out);
 
 #ifdef __cplusplus

@@ -46,7 +46,8 @@ CLAIM_OUT = np.dtype([("nodepool", "<u4"), ("n_pods", "<u4"), ("types", RANGE), 
 REQ_OUT = np.dtype([("key", "<u4"), ("complement", "u1"), ("has_gt", "u1"), ("has_lt", "u1"), ("gt", "<i8"), ("lt", "<i8"),
                     ("values", RANGE)], align=True)
 CANDIDATE_RECORD = np.dtype([("candidate", "<i4"), ("decision", "<i4"), ("nodepool", "<u4"), ("n_types", "<u4"),
-                             ("candidate_price", "<f8"), ("type_mask", "<u8", (13,)), ("spot_only", "u1"), ("pad", "u1", (7,))], align=True)
+                             ("candidate_price", "<f8"), ("type_mask", "<u8", (13,)), ("zone_mask", "<u8"), ("ct_mask", "<u8"),
+                             ("spot_only", "u1"), ("pad", "u1", (7,))], align=True)
 EC2_DEVICE = np.dtype([("name", "<u4"), ("manufacturer", "<u4"), ("count", "<i8"), ("memory_mib", "<i8")], align=True)
 EC2_TYPE = np.dtype([("name", "<u4"), ("arch", "<u4"), ("first_arch_is_arm64", "u1"), ("hypervisor", "<u4"), ("cpu_manufacturer", "<u4"),
                      ("vcpus", "<i8"), ("memory_mib", "<i8"), ("encryption_in_transit", "u1"), ("ebs_max_bandwidth_mbps", "<i8"),
@@ -422,3 +423,31 @@ class ResultBuffers:
                 claim["requirements"] = reqs
             out["claims"].append(claim)
         return out
+
+
+def build_candidates(candidates, spot_to_spot=False, shard=0, n_shards=1):
+    a = np.array(list(candidates), dtype="<i4")
+    d = CandidatesDesc()
+    d.candidates, d.n_candidates = _ptr(a), a.shape[0]
+    d.spot_to_spot_enabled = 1 if spot_to_spot else 0
+    d.shard, d.n_shards = shard, n_shards
+    return Built(d, [a])
+
+
+class DecisionBuffer:
+    def __init__(self, cap_types=1024):
+        self.type_ids = np.zeros(cap_types, "<u4")
+        self.dec = Decision()
+        self.dec.type_ids, self.dec.cap_type_ids = _ptr(self.type_ids), cap_types
+
+    def decode(self):
+        d = self.dec
+        return {"decision": d.decision, "n_candidates": d.n_candidates, "first_candidate": d.first_candidate, "nodepool": d.nodepool,
+                "types": self.type_ids[:min(d.n_types, d.cap_type_ids)].tolist(), "spot_only": int(d.replacement_spot_only),
+                "candidate_price": d.candidate_price, "simulations": int(d.simulations)}
+
+
+def record_tuple(r):
+    """The comparable part of a kg_candidate_record (zone_mask / ct_mask are library-internal)."""
+    return (int(r["candidate"]), int(r["decision"]), int(r["nodepool"]), int(r["n_types"]), float(r["candidate_price"]),
+            tuple(int(x) for x in r["type_mask"]), int(r["spot_only"]))

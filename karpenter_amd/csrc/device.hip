@@ -64,6 +64,18 @@ __global__ void __launch_bounds__(NT) k_solve(DevProblem Pin, const SimState* si
   if ((P.stats & 2) && threadIdx.x == 0) { S.counters[24] = clock64() - c0; S.counters[25] = wall_clock64() - w0; }
 }
 
+// k_sim_init: one workgroup per simulation copies the pristine state image into its slot and applies the patches
+__global__ void __launch_bounds__(256) k_sim_init(DevProblem P, SimBatch B) {
+  sim_init_copy(B, blockIdx.x, threadIdx.x, blockDim.x);
+  __syncthreads();
+  sim_init_patch(P, B, blockIdx.x, threadIdx.x, blockDim.x);
+}
+// k_sim_gather: one thread per simulation condenses the outcome into a SimResult
+__global__ void __launch_bounds__(64) k_sim_gather(DevProblem P, SimBatch B, const SimState* sims) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (uint32_t)B.nsims) sim_gather(P, B, sims[i], i);
+}
+
 namespace hal {
 
 static void ck(hipError_t e, const char* what) {
@@ -120,6 +132,18 @@ void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const ui
   else if (block >= 512) hipLaunchKernelGGL((k_solve<512>), dim3(nsims), dim3(512), 0, 0, P, sims, nqueue);
   else hipLaunchKernelGGL((k_solve<256>), dim3(nsims), dim3(256), 0, 0, P, sims, nqueue);
   ck(hipGetLastError(), "solve launch");
+  *ms = t.stop();
+}
+void launch_sim_init(const DevProblem& P, const SimBatch& B, float* ms) {
+  Timer t;
+  if (B.nsims) hipLaunchKernelGGL(k_sim_init, dim3(B.nsims), dim3(256), 0, 0, P, B);
+  ck(hipGetLastError(), "sim init launch");
+  *ms = t.stop();
+}
+void launch_sim_gather(const DevProblem& P, const SimBatch& B, const SimState* sims, float* ms) {
+  Timer t;
+  if (B.nsims) hipLaunchKernelGGL(k_sim_gather, dim3((B.nsims + 63) / 64), dim3(64), 0, 0, P, B, sims);
+  ck(hipGetLastError(), "sim gather launch");
   *ms = t.stop();
 }
 const char* backend() { return "hip-gfx950"; }

@@ -40,5 +40,16 @@ void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const ui
   }
   *ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
+void launch_sim_init(const DevProblem& P, const SimBatch& B, float* ms) {
+  for (int i = 0; i < B.nsims; ++i) {
+    for (uint32_t t = 0; t < 64; ++t) sim_init_copy(B, (uint32_t)i, t, 64);
+    for (uint32_t t = 0; t < 64; ++t) sim_init_patch(P, B, (uint32_t)i, t, 64);
+  }
+  *ms = 0;
+}
+void launch_sim_gather(const DevProblem& P, const SimBatch& B, const SimState* sims, float* ms) {
+  for (int i = 0; i < B.nsims; ++i) sim_gather(P, B, sims[i], (uint32_t)i);
+  *ms = 0;
+}
 const char* backend() { return "emu"; }
 }  // namespace kg::hal

@@ -271,8 +271,11 @@ struct Compiled {
   DeviceBuffer prob_dev, state_dev, sims_dev;
   SimState sim{};  // device pointers
   std::vector<uint8_t> state_image;
+  size_t state_bytes = 0;
+  uint32_t qcap = 0;
+  std::vector<uint32_t> queue_order, pod_variant0;  // pods in Queue order; initial variant of every pod
   size_t o_nreq, o_creq, o_chead, o_chstamp, o_cmask, o_cbits, o_cmeta, o_cnpods, o_ctmpl, o_order, o_remaining, o_gcount, o_gdom, o_gpos, o_hcount, o_hpos, o_queue,
-      o_podkind, o_podindex, o_podreason, o_scratch, o_header, o_counters, o_nqueue;
+      o_podkind, o_excl, o_podindex, o_podreason, o_scratch, o_header, o_counters, o_nqueue;
   ~Compiled() {
     hal::dfree(prob_dev.ptr);
     hal::dfree(state_dev.ptr);
@@ -280,6 +283,7 @@ struct Compiled {
   }
 };
 
+static SimState sim_at(const Compiled& C, uint8_t* base);
 static int find_slot(const Compiled& C, uint32_t key) {
   for (size_t a = 0; a < C.slot_key.size(); ++a) if (C.slot_key[a] == key) return (int)a;
   return -1;
@@ -330,6 +334,7 @@ struct SolveInputs {
   kg_cluster* cluster;
   const kg_nodepools_desc* nps;
   ParsedPods* pending;
+  int sim_cmax = 0;  // > 0: compile for a batch of simulations over subsets of `pending` with at most this many pods each
 };
 
 // Builds every device table for one Solve over `in.pending`.
@@ -843,8 +848,11 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   std::vector<Group> dgroups(std::max(G, 1));
   std::vector<uint64_t> gdom0(std::max(G, 1), 0), gpos0(std::max(G, 1), 0);
   std::vector<int32_t> gcount0((size_t)std::max(G, 1) * 64, 0);
-  const int Cmax = std::max(P, 1);
+  const bool sim_mode = in.sim_cmax > 0;
+  const int Cmax = sim_mode ? in.sim_cmax : std::max(P, 1);
   C.Cmax = Cmax;
+  if (sim_mode && G > 0) throw Unsupported("consolidation simulations with topology spread / pod (anti-)affinity are not on the device path yet");
+  if (sim_mode && tmpl_minv_mask) throw Unsupported("consolidation simulations with minValues NodePools are not on the device path yet");
   const int H = N + Cmax;
   std::vector<int32_t> hcount0((size_t)std::max(GH, 1) * H, 0), hpos0(std::max(GH, 1), 0);
   if (G > 0) {
@@ -1062,31 +1070,49 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   C.o_remaining = SA.add(remaining0);
   C.o_gcount = SA.add(gcount0); C.o_gdom = SA.add(gdom0); C.o_gpos = SA.add(gpos0); C.o_hcount = SA.add(hcount0); C.o_hpos = SA.add(hpos0);
   // Queue ring entries {pod, variant, lastLen epoch, lastLen value}
-  std::vector<uint32_t> queue((size_t)(P + 1) * 4, 0);
-  for (int i = 0; i < P; ++i) { queue[(size_t)i * 4] = queue0[i]; queue[(size_t)i * 4 + 1] = pod_variant0[queue0[i]]; }
+  const int PR = sim_mode ? Cmax : std::max(P, 1);  // pod result rows
+  C.qcap = (uint32_t)(sim_mode ? Cmax : P) + 1;
+  std::vector<uint32_t> queue((size_t)C.qcap * 4, 0);
+  if (!sim_mode) for (int i = 0; i < P; ++i) { queue[(size_t)i * 4] = queue0[i]; queue[(size_t)i * 4 + 1] = pod_variant0[queue0[i]]; }
+  C.queue_order = queue0;
+  C.pod_variant0 = pod_variant0;
   C.o_queue = SA.add(queue);
-  C.o_podkind = SA.reserve((size_t)std::max(P, 1));
-  C.o_podindex = SA.reserve((size_t)std::max(P, 1) * 4);
-  C.o_podreason = SA.reserve((size_t)std::max(P, 1) * 4);
+  C.o_podkind = SA.reserve((size_t)PR);
+  C.o_podindex = SA.reserve((size_t)PR * 4);
+  C.o_podreason = SA.reserve((size_t)PR * 4);
+  C.o_excl = SA.reserve((size_t)NW * 8);
   C.o_scratch = SA.reserve((size_t)(TW + 1) * Cmax * 8);
   C.o_header = SA.add(header);
   C.o_counters = SA.add(counters);
   C.o_nqueue = SA.add(nqueue);
-  C.state_dev.bytes = SA.bytes.size();
+  SA.bytes.resize((SA.bytes.size() + 255) & ~size_t(255), 0);
+  C.state_bytes = SA.bytes.size();
+  C.state_image = std::move(SA.bytes);
+  if (sim_mode) return Cp;  // the caller lays out one slot per simulation
+  C.state_dev.bytes = C.state_bytes;
   C.state_dev.ptr = hal::dmalloc(C.state_dev.bytes);
-  hal::h2d(C.state_dev.ptr, SA.bytes.data(), C.state_dev.bytes);
-  auto sptr = [&](size_t off) { return (uint8_t*)C.state_dev.ptr + off; };
+  hal::h2d(C.state_dev.ptr, C.state_image.data(), C.state_dev.bytes);
+  C.sim = sim_at(C, (uint8_t*)C.state_dev.ptr);
   SimState& St = C.sim;
+  C.sims_dev.bytes = sizeof(SimState);
+  C.sims_dev.ptr = hal::dmalloc(sizeof(SimState));
+  hal::h2d(C.sims_dev.ptr, &St, sizeof(SimState));
+  return Cp;
+}
+
+// SimState whose arrays live in the state slot starting at `base`
+static SimState sim_at(const Compiled& C, uint8_t* base) {
+  auto sptr = [&](size_t off) { return base + off; };
+  SimState St{};
   St.nreq = (int64_t*)sptr(C.o_nreq); St.c_req = (int64_t*)sptr(C.o_creq); St.c_head = (int64_t*)sptr(C.o_chead); St.c_hstamp = (uint32_t*)sptr(C.o_chstamp); St.c_mask = (uint64_t*)sptr(C.o_cmask); St.c_bits = (uint64_t*)sptr(C.o_cbits);
   St.c_meta = (uint32_t*)sptr(C.o_cmeta); St.c_npods = (uint32_t*)sptr(C.o_cnpods); St.c_tmpl = (uint16_t*)sptr(C.o_ctmpl); St.c_stamp = (uint32_t*)sptr(C.o_order);
   St.remaining = (int64_t*)sptr(C.o_remaining); St.gcount = (int32_t*)sptr(C.o_gcount); St.gdom = (uint64_t*)sptr(C.o_gdom); St.gpos = (uint64_t*)sptr(C.o_gpos);
   St.hcount = (int32_t*)sptr(C.o_hcount); St.hpos = (int32_t*)sptr(C.o_hpos); St.queue = (uint32_t*)sptr(C.o_queue); St.pod_kind = (uint8_t*)sptr(C.o_podkind);
   St.pod_index = (int32_t*)sptr(C.o_podindex); St.pod_reason = (uint32_t*)sptr(C.o_podreason); St.scratch = (uint64_t*)sptr(C.o_scratch);
   St.header = (uint32_t*)sptr(C.o_header); St.counters = (uint64_t*)sptr(C.o_counters);
-  C.sims_dev.bytes = sizeof(SimState);
-  C.sims_dev.ptr = hal::dmalloc(sizeof(SimState));
-  hal::h2d(C.sims_dev.ptr, &St, sizeof(SimState));
-  return Cp;
+  St.excl = (const uint64_t*)sptr(C.o_excl);
+  St.n_shared = (uint32_t)C.P; St.pod_base = 0; St.qcap = C.qcap;
+  return St;
 }
 
 // ------------------------------------------------------------------ truncation (InstanceTypes.OrderByPrice / Truncate / SatisfiesMinValues)
@@ -1485,6 +1511,394 @@ int32_t kg_solve(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, 
   ctx->stats.device_ms_total += ms_pre + ms_solve;
   ctx->stats.host_compile_ms_total += std::chrono::duration<double, std::milli>(t1 - t0).count();
   return W.overflow ? fail(ctx, KG_ENOMEM, "result buffers too small (see needed_*)") : KG_OK;
+  KG_GUARD_END(ctx)
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ consolidation (disruption simulation batches)
+namespace {
+
+struct CandInfo {
+  bool ok = false;       // price known (instance type resolvable, a compatible offering exists)
+  double price = 0;      // cheapest offering compatible with the node's labels (getCandidatePrices)
+  int type = -1;
+  bool spot = false;
+};
+
+// the replacement NodeClaim of one simulation after computeConsolidation's filters
+struct Replacement {
+  int decision = KG_DECISION_NOOP;
+  uint32_t nodepool = 0;
+  std::vector<uint32_t> types;  // price ordered
+  uint64_t zmask = ~0ull, ctmask = ~0ull;
+  double candidate_price = 0;
+  bool spot_only = false;
+};
+
+uint64_t allowed1(uint32_t meta, uint64_t word) {
+  if (!(meta & RM_PRESENT)) return ~0ull;
+  return (meta & RM_COMPL) ? ~word : word;
+}
+
+void order_by_price(const kg_catalog* cat, std::vector<uint32_t>* types, uint64_t zmask, uint64_t ctmask) {
+  std::vector<std::pair<double, uint32_t>> keyed;
+  for (uint32_t t : *types) keyed.push_back({cheapest_price(cat->types[t], zmask, ctmask), t});
+  std::stable_sort(keyed.begin(), keyed.end(), [&](auto& a, auto& b) {
+    if (a.first == b.first) return cat->types[a.second].name < cat->types[b.second].name;
+    return a.first < b.first;
+  });
+  types->clear();
+  for (auto& kv : keyed) types->push_back(kv.second);
+}
+
+// Offerings.Available().WorstLaunchPrice(reqs)
+double worst_launch_price(const CatType& t, uint64_t zmask, uint64_t ctmask, int spot, int od) {
+  for (int want : {spot, od}) {
+    if (want < 0 || !((ctmask >> want) & 1)) continue;
+    bool any = false;
+    double worst = 0;
+    for (auto& o : t.offerings) {
+      if (!o.available || (int)o.ct != want || !((zmask >> o.zone) & 1)) continue;
+      if (!any || o.price > worst) { worst = o.price; any = true; }
+    }
+    if (any) return worst;
+  }
+  return std::numeric_limits<double>::max();
+}
+
+void remove_by_price(const kg_catalog* cat, Replacement* r, double max_price, int spot, int od) {
+  std::vector<uint32_t> kept;
+  for (uint32_t t : r->types) if (worst_launch_price(cat->types[t], r->zmask, r->ctmask, spot, od) < max_price) kept.push_back(t);
+  r->types.swap(kept);
+}
+
+}  // namespace
+
+static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, kg_cluster* cluster, const kg_pods_desc* pending,
+                                const kg_nodepools_desc* nodepools, const kg_candidates_desc* cands, bool multi, kg_candidate_record* records,
+                                uint32_t cap_records, uint32_t* n_records, double* device_ms) {
+  if (!ctx || !catalogs || n_catalogs == 0 || !cluster || !nodepools || !cands || !n_records || (!records && cap_records)) return KG_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  KG_GUARD_BEGIN
+  if (n_catalogs != 1) throw Unsupported("one catalog per solve on the device path");
+  kg_catalog* cat = catalogs[0];
+  Vocab& V = ctx->V;
+  const uint32_t n = cands->n_candidates;
+  const int shards = std::max(cands->n_shards, 1);
+  check(cands->shard >= 0 && cands->shard < shards, "shard index");
+  for (uint32_t i = 0; i < n; ++i) check(cands->candidates[i] >= 0 && cands->candidates[i] < (int)cluster->nodes.size(), "candidate node index");
+  *n_records = 0;
+  if (device_ms) *device_ms = 0;
+
+  // ---- pod universe: pending pods, pods of deleting nodes, then the candidates' reschedulable pods in candidate order
+  ParsedPods pend;
+  parse_pods(ctx, pending, &pend);
+  ParsedPods U;
+  U.classes = pend.classes;
+  const uint32_t cls_off = (uint32_t)U.classes.size();
+  U.classes.insert(U.classes.end(), cluster->bound.classes.begin(), cluster->bound.classes.end());
+  std::vector<uint8_t> nonpending;
+  for (auto& p : pend.pods) { U.pods.push_back(p); nonpending.push_back(0); }
+  std::vector<std::vector<uint32_t>> pods_of_node(cluster->nodes.size());
+  for (size_t i = 0; i < cluster->bound.pods.size(); ++i)
+    if (cluster->bound.pods[i].reschedulable) pods_of_node[cluster->bound.pods[i].node].push_back((uint32_t)i);
+  auto add_bound = [&](uint32_t bi) {
+    PodRef pr = cluster->bound.pods[bi];
+    pr.cls += cls_off;
+    U.pods.push_back(std::move(pr));
+    nonpending.push_back(1);
+  };
+  std::vector<uint8_t> is_cand(cluster->nodes.size(), 0);
+  const uint32_t n_used = multi ? std::min<uint32_t>(n, 100) : n;
+  for (uint32_t i = 0; i < n_used; ++i) is_cand[cands->candidates[i]] = 1;
+  for (size_t nd = 0; nd < cluster->nodes.size(); ++nd)
+    if (cluster->nodes[nd].deleting && !is_cand[nd]) for (uint32_t bi : pods_of_node[nd]) add_bound(bi);
+  const uint32_t n_shared = (uint32_t)U.pods.size();
+  std::vector<uint32_t> cand_begin(n_used + 1, n_shared);
+  for (uint32_t i = 0; i < n_used; ++i) {
+    cand_begin[i] = (uint32_t)U.pods.size();
+    for (uint32_t bi : pods_of_node[cands->candidates[i]]) add_bound(bi);
+  }
+  cand_begin[n_used] = (uint32_t)U.pods.size();
+
+  // ---- units of this shard
+  struct Unit { uint32_t id; uint32_t pod_lo, pod_hi; bool skip; };
+  std::vector<Unit> units;
+  const uint32_t lo = multi ? 1 : 0, hi = multi ? n_used : n;
+  for (uint32_t u = lo; u < hi; ++u) {
+    if ((int)((u - lo) % shards) != cands->shard) continue;
+    Unit un{u, multi ? n_shared : cand_begin[u], cand_begin[u + 1], false};
+    if (!multi && un.pod_hi == un.pod_lo) un.skip = true;  // no reschedulable pods: emptiness handles the node
+    units.push_back(un);
+  }
+  *n_records = (uint32_t)units.size();
+  if (units.size() > cap_records) return fail(ctx, KG_ENOMEM, "record buffer too small");
+  for (size_t k = 0; k < units.size(); ++k) {
+    std::memset(&records[k], 0, sizeof(kg_candidate_record));
+    records[k].candidate = (int32_t)units[k].id;
+  }
+  std::vector<uint32_t> live;
+  int cmax = 1;
+  for (size_t k = 0; k < units.size(); ++k)
+    if (!units[k].skip) { live.push_back((uint32_t)k); cmax = std::max(cmax, (int)(n_shared + units[k].pod_hi - units[k].pod_lo)); }
+  if (live.empty()) return KG_OK;
+
+  // ---- compile once; every simulation shares the problem tables
+  SolveInputs in{ctx, cat, cluster, nodepools, &U};
+  in.sim_cmax = cmax;
+  auto C = compile_problem(in, false);
+  const int N = C->N, NW = std::max((N + 63) / 64, 1), R = C->R, NP = C->NP;
+  std::vector<int> pos_of_node(cluster->nodes.size(), -1);
+  for (int i = 0; i < N; ++i) pos_of_node[C->node_order[i]] = i;
+  std::vector<uint32_t> rank(std::max<size_t>(U.pods.size(), 1), 0);
+  for (size_t i = 0; i < C->queue_order.size() && i < U.pods.size(); ++i) rank[C->queue_order[i]] = (uint32_t)i;
+  std::vector<uint64_t> node_uninit(NW, 0);
+  for (int i = 0; i < N; ++i) if (!cluster->nodes[C->node_order[i]].initialized) node_uninit[i >> 6] |= 1ull << (i & 63);
+  bool any_limits = false;
+  for (auto& tp : C->templates) any_limits |= tp.has_limits && !tp.limits.empty();
+  std::vector<int> ract(V.resources.size(), -1);
+  for (int r = 0; r < R; ++r) ract[C->act_res[r]] = r;
+
+  float ms_pre = 0;
+  hal::launch_prepass(C->dp, C->pre, &ms_pre);
+  double ms_total = ms_pre;
+  const size_t stride = C->state_bytes;
+  const size_t budget = (size_t)8 << 30;
+  const size_t max_batch = std::max<size_t>(1, std::min<size_t>(live.size(), budget / stride > 1 ? budget / stride - 1 : 1));
+  std::vector<SimResult> results(live.size());
+  for (size_t b0 = 0; b0 < live.size(); b0 += max_batch) {
+    const size_t nb = std::min(max_batch, live.size() - b0);
+    std::vector<uint32_t> q_off(nb + 1, 0), x_off(nb + 1, 0), x_node;
+    std::vector<uint32_t> q_ent;
+    std::vector<int64_t> rem_adj(any_limits ? nb * (size_t)R * NP : 0, 0);
+    std::vector<SimState> sims(nb);
+    DeviceBuffer arena;
+    arena.bytes = (nb + 1) * stride;
+    arena.ptr = hal::dmalloc(arena.bytes);
+    struct Free { void* p; ~Free() { hal::dfree(p); } } free_arena{arena.ptr};
+    hal::h2d(arena.ptr, C->state_image.data(), stride);
+    for (size_t k = 0; k < nb; ++k) {
+      const Unit& un = units[live[b0 + k]];
+      std::vector<uint32_t> pods;
+      for (uint32_t p = 0; p < n_shared; ++p) pods.push_back(p);
+      for (uint32_t p = un.pod_lo; p < un.pod_hi; ++p) pods.push_back(p);
+      std::sort(pods.begin(), pods.end(), [&](uint32_t a, uint32_t b) { return rank[a] < rank[b]; });
+      q_off[k] = (uint32_t)(q_ent.size() / 4);
+      for (uint32_t p : pods) { q_ent.push_back(p); q_ent.push_back(C->pod_variant0[p]); q_ent.push_back(0); q_ent.push_back(0); }
+      x_off[k] = (uint32_t)x_node.size();
+      const uint32_t c0 = multi ? 0 : un.id, c1 = un.id + 1;
+      for (uint32_t ci = c0; ci < c1; ++ci) {
+        const int nd = cands->candidates[ci];
+        if (pos_of_node[nd] >= 0) x_node.push_back((uint32_t)pos_of_node[nd]);
+        if (any_limits && pos_of_node[nd] >= 0) {
+          // the scheduler of a simulation does not charge the candidates against their NodePool's limits
+          uint32_t npv = UINT32_MAX;
+          for (auto& kv : cluster->nodes[nd].labels) if (kv.first == ctx->kNodePool) npv = kv.second;
+          if (npv == UINT32_MAX) continue;
+          for (int t = 0; t < NP; ++t) {
+            const auto& tp = C->templates[t];
+            if (!(tp.has_limits && !tp.limits.empty()) || V.vals[ctx->kNodePool].strs[npv] != tp.name) continue;
+            for (auto& kv : cluster->nodes[nd].capacity) {
+              bool limited = false;
+              for (auto& lv : tp.limits) limited |= lv.first == kv.first;
+              if (limited && ract[kv.first] >= 0) rem_adj[k * (size_t)R * NP + (size_t)ract[kv.first] * NP + t] += kv.second;
+            }
+          }
+        }
+      }
+      sims[k] = sim_at(*C, (uint8_t*)arena.ptr + (k + 1) * stride);
+      sims[k].n_shared = n_shared;
+      sims[k].pod_base = un.pod_lo;
+    }
+    q_off[nb] = (uint32_t)(q_ent.size() / 4);
+    x_off[nb] = (uint32_t)x_node.size();
+    // one upload for all the per-simulation tables
+    Arena PA;
+    const size_t o_qoff = PA.add(q_off), o_qent = PA.add(q_ent, 4), o_xoff = PA.add(x_off), o_xnode = PA.add(x_node), o_rem = PA.add(rem_adj),
+                 o_nq = PA.reserve(nb * 4), o_res = PA.reserve(nb * sizeof(SimResult)), o_np = PA.add(nonpending), o_un = PA.add(node_uninit),
+                 o_sims = PA.add(sims);
+    DeviceBuffer patch;
+    patch.bytes = PA.bytes.size();
+    patch.ptr = hal::dmalloc(patch.bytes);
+    Free free_patch{patch.ptr};
+    hal::h2d(patch.ptr, PA.bytes.data(), patch.bytes);
+    auto pp = [&](size_t off) { return (uint8_t*)patch.ptr + off; };
+    SimBatch B{};
+    B.arena = (uint8_t*)arena.ptr; B.stride = stride; B.o_queue = C->o_queue; B.o_excl = C->o_excl; B.o_remaining = C->o_remaining;
+    B.q_off = (const uint32_t*)pp(o_qoff); B.q_ent = (const uint4*)pp(o_qent); B.x_off = (const uint32_t*)pp(o_xoff); B.x_node = (const uint32_t*)pp(o_xnode);
+    B.rem_adj = any_limits ? (const int64_t*)pp(o_rem) : nullptr; B.nqueue = (uint32_t*)pp(o_nq); B.results = (SimResult*)pp(o_res);
+    B.pod_nonpending = (const uint8_t*)pp(o_np); B.node_uninit = (const uint64_t*)pp(o_un); B.nsims = (int)nb;
+    float ms_i = 0, ms_s = 0, ms_g = 0;
+    hal::launch_sim_init(C->dp, B, &ms_i);
+    hal::launch_solve(C->dp, (const SimState*)pp(o_sims), (int)nb, B.nqueue, ctx->sim_block_threads, &ms_s);
+    hal::launch_sim_gather(C->dp, B, (const SimState*)pp(o_sims), &ms_g);
+    hal::d2h(results.data() + b0, pp(o_res), nb * sizeof(SimResult));
+    ms_total += ms_i + ms_s + ms_g;
+    ctx->stats.kernel_launches += 3;
+    ctx->stats.solves += nb;
+  }
+  if (device_ms) *device_ms = ms_total;
+  ctx->stats.device_ms_total += ms_total;
+
+  // ---- computeConsolidation's decision logic per simulation (prices are float64 catalog data: host side)
+  const int spot = V.vals[ctx->kCT].find("spot"), od = V.vals[ctx->kCT].find("on-demand");
+  std::unordered_map<std::string, int> type_by_name;
+  for (size_t t = 0; t < cat->types.size(); ++t) type_by_name.emplace(cat->types[t].name, (int)t);
+  std::vector<CandInfo> cinfo(n_used);
+  for (uint32_t i = 0; i < n_used; ++i) {
+    const CNode& nd = cluster->nodes[cands->candidates[i]];
+    int zone = -1, ctv = -1, zid = -1, itv = -1;
+    for (auto& kv : nd.labels) {
+      if (kv.first == ctx->kZone) zone = (int)kv.second;
+      if (kv.first == ctx->kCT) ctv = (int)kv.second;
+      if (kv.first == ctx->kZid) zid = (int)kv.second;
+      if (kv.first == ctx->kInstanceType) itv = (int)kv.second;
+    }
+    CandInfo& ci = cinfo[i];
+    ci.spot = ctv >= 0 && ctv == spot;
+    if (itv < 0) continue;
+    auto f = type_by_name.find(V.vals[ctx->kInstanceType].strs[itv]);
+    if (f == type_by_name.end()) continue;
+    ci.type = f->second;
+    for (auto& o : cat->types[ci.type].offerings) {
+      if (zone >= 0 && (int)o.zone != zone) continue;
+      if (ctv >= 0 && (int)o.ct != ctv) continue;
+      if (zid >= 0 && o.zid >= 0 && o.zid != zid) continue;
+      if (!ci.ok || o.price < ci.price) { ci.price = o.price; ci.ok = true; }
+    }
+  }
+  const uint8_t* zone_zid = cat->tab.image.bytes.data() + cat->tab.o_zone_zid;
+  for (size_t li = 0; li < live.size(); ++li) {
+    const Unit& un = units[live[li]];
+    const SimResult& sr = results[li];
+    kg_candidate_record& rec = records[live[li]];
+    Replacement rp;
+    const uint32_t c0 = multi ? 0 : un.id, c1 = un.id + 1;
+    if (sr.errors == 0 && sr.nclaims == 0) rp.decision = KG_DECISION_DELETE;
+    else if (sr.errors == 0 && sr.nclaims == 1) {
+      bool priced = true, all_spot = true;
+      double price = 0;
+      for (uint32_t ci = c0; ci < c1; ++ci) { priced &= cinfo[ci].ok; price += cinfo[ci].price; all_spot &= cinfo[ci].spot; }
+      if (priced) {
+        rp.candidate_price = price;
+        rp.nodepool = C->templates[sr.tmpl].index;
+        rp.zmask = allowed1(sr.zone_meta, sr.zone_word);
+        rp.ctmask = allowed1(sr.ct_meta, sr.ct_word);
+        const uint64_t zidm = allowed1(sr.zid_meta, sr.zid_word);
+        if (sr.zid_meta & RM_PRESENT)
+          for (int z = 0; z < 64; ++z) if (zone_zid[z] != 0xFF && !((zidm >> zone_zid[z]) & 1)) rp.zmask &= ~(1ull << z);
+        for (int w = 0; w < C->TW && w < KG_TWLDS; ++w)
+          for (uint64_t m = sr.mask[w]; m; m &= m - 1) rp.types.push_back((uint32_t)(w * 64 + __builtin_ctzll(m)));
+        order_by_price(cat, &rp.types, rp.zmask, rp.ctmask);
+        if (nodepools->max_instance_types > 0 && rp.types.size() > (size_t)nodepools->max_instance_types) rp.types.resize(nodepools->max_instance_types);
+        const bool has_spot = spot >= 0 && ((rp.ctmask >> spot) & 1), has_od = od >= 0 && ((rp.ctmask >> od) & 1);
+        if (all_spot && has_spot) {
+          // computeSpotToSpotConsolidation
+          if (cands->spot_to_spot_enabled) {
+            rp.ctmask = 1ull << spot;
+            std::vector<uint32_t> compat;
+            for (uint32_t t : rp.types) if (cheapest_price(cat->types[t], rp.zmask, rp.ctmask) != std::numeric_limits<double>::max()) compat.push_back(t);
+            rp.types.swap(compat);
+            remove_by_price(cat, &rp, price, spot, od);
+            rp.spot_only = true;
+            if (!rp.types.empty()) {
+              if (c1 - c0 > 1) rp.decision = KG_DECISION_REPLACE;
+              else if (rp.types.size() >= 15) { rp.types.resize(15); rp.decision = KG_DECISION_REPLACE; }
+            }
+          }
+        } else {
+          remove_by_price(cat, &rp, price, spot, od);
+          if (!rp.types.empty()) {
+            if (has_spot && has_od) { rp.ctmask = 1ull << spot; rp.spot_only = true; }
+            rp.decision = KG_DECISION_REPLACE;
+          }
+        }
+        if (multi && rp.decision == KG_DECISION_REPLACE) {
+          // filterOutSameType
+          double max_price = std::numeric_limits<double>::max();
+          for (uint32_t t : rp.types)
+            for (uint32_t ci = c0; ci < c1; ++ci)
+              if (cinfo[ci].ok && cinfo[ci].type == (int)t && cinfo[ci].price < max_price) max_price = cinfo[ci].price;
+          remove_by_price(cat, &rp, max_price, spot, od);
+          if (rp.types.empty()) rp.decision = KG_DECISION_NOOP;
+        }
+      }
+    }
+    rec.decision = rp.decision;
+    if (rp.decision == KG_DECISION_REPLACE) {
+      rec.nodepool = rp.nodepool;
+      rec.n_types = (uint32_t)rp.types.size();
+      rec.candidate_price = rp.candidate_price;
+      rec.spot_only = rp.spot_only;
+      rec.zone_mask = rp.zmask;
+      rec.ct_mask = rp.ctmask;
+      for (uint32_t t : rp.types) {
+        if (t >= 13 * 64) throw Unsupported("more than 832 instance types in a consolidation record");
+        rec.type_mask[t >> 6] |= 1ull << (t & 63);
+      }
+    }
+  }
+  return KG_OK;
+  KG_GUARD_END(ctx)
+}
+
+extern "C" {
+
+int32_t kg_consolidate_single(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, kg_cluster* cluster, const kg_pods_desc* pending,
+                              const kg_nodepools_desc* nodepools, const kg_candidates_desc* cands, kg_candidate_record* records,
+                              uint32_t cap_records, uint32_t* n_records, double* device_ms) {
+  return consolidate_impl(ctx, catalogs, n_catalogs, cluster, pending, nodepools, cands, false, records, cap_records, n_records, device_ms);
+}
+
+int32_t kg_consolidate_multi(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, kg_cluster* cluster, const kg_pods_desc* pending,
+                             const kg_nodepools_desc* nodepools, const kg_candidates_desc* cands, kg_candidate_record* records,
+                             uint32_t cap_records, uint32_t* n_records, double* device_ms) {
+  return consolidate_impl(ctx, catalogs, n_catalogs, cluster, pending, nodepools, cands, true, records, cap_records, n_records, device_ms);
+}
+
+// SingleNodeConsolidation.ComputeCommand (first candidate in order with a command) / the binary search of
+// MultiNodeConsolidation.firstNConsolidationOption, replayed over records gathered from every shard.
+int32_t kg_consolidate_select(kg_ctx* ctx, kg_catalog* catalog, int32_t multi, const kg_candidate_record* records, uint32_t n_records,
+                              uint32_t n_candidates, kg_decision* out) {
+  if (!ctx || !catalog || !out || (!records && n_records)) return KG_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  KG_GUARD_BEGIN
+  const kg_candidate_record* win = nullptr;
+  int win_n = 0;
+  if (!multi) {
+    for (uint32_t i = 0; i < n_records; ++i)
+      if (records[i].decision != KG_DECISION_NOOP && (!win || records[i].candidate < win->candidate)) win = &records[i];
+    win_n = 1;
+  } else if (n_candidates >= 2) {
+    std::unordered_map<int, const kg_candidate_record*> by_mid;
+    for (uint32_t i = 0; i < n_records; ++i) by_mid[records[i].candidate] = &records[i];
+    int mn = 1, mx = (int)std::min<uint32_t>(n_candidates, 100) - 1;
+    while (mn <= mx) {
+      const int mid = (mn + mx) / 2;
+      auto f = by_mid.find(mid);
+      if (f == by_mid.end()) throw kgdesc::DescError("multi-node selection: the record of a probed prefix is missing");
+      if (f->second->decision != KG_DECISION_NOOP) { win = f->second; win_n = mid + 1; mn = mid + 1; } else mx = mid - 1;
+    }
+  }
+  out->decision = win ? win->decision : KG_DECISION_NOOP;
+  out->n_candidates = win ? win_n : 0;
+  out->first_candidate = win ? (multi ? 0 : win->candidate) : -1;
+  out->nodepool = win ? win->nodepool : 0;
+  out->n_types = 0;
+  out->replacement_spot_only = win ? win->spot_only : 0;
+  out->candidate_price = win && win->decision == KG_DECISION_REPLACE ? win->candidate_price : 0;
+  out->simulations = n_records;
+  out->device_ms = 0;
+  if (win && win->decision == KG_DECISION_REPLACE) {
+    std::vector<uint32_t> types;
+    for (int w = 0; w < 13; ++w)
+      for (uint64_t m = win->type_mask[w]; m; m &= m - 1) types.push_back((uint32_t)(w * 64 + __builtin_ctzll(m)));
+    for (uint32_t t : types) check(t < catalog->types.size(), "record type id outside the catalog");
+    order_by_price(catalog, &types, win->zone_mask, win->ct_mask);
+    for (uint32_t t : types) { if (out->n_types < out->cap_type_ids && out->type_ids) out->type_ids[out->n_types] = t; out->n_types++; }
+  }
+  return KG_OK;
   KG_GUARD_END(ctx)
 }
 

@@ -205,6 +205,8 @@ struct SimState {
   uint32_t* pod_reason; // [P]
   uint64_t* scratch;  // [TW+1][Cmax] candidate option masks of the survivors; row TW: per-claim visit statistic
   uint32_t* header;   // [16]: 0 nclaims, 1 relaxations, 2-5 the claim touched after the last sort (id, old pods, old stamp, new)
+  const uint64_t* excl; // [NW] existing nodes left out of this simulation (consolidation candidates)
+  uint32_t n_shared, pod_base, qcap;  // pods [0,n_shared) and [pod_base, ...) take part; result rows are local indices
   uint64_t* counters; // [32]: 8.. phase timers and scan statistics when stats&2; [0..3]: visited_existing, visited_claims, visited_claim_types, new_claim_scans
 };
 
@@ -708,6 +710,7 @@ template <bool COMMIT>
 KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, uint32_t n, uint32_t* reason) {
   const Variant& v = sh.vc.v;
   const uint32_t wi = n >> 6, bi = n & 63;
+  if ((S.excl[wi] >> bi) & 1) return false;  // a candidate of this simulation: not a state node
   if (!((P.ntol[(size_t)v.tolset * P.NW + wi] >> bi) & 1)) { *reason |= 1; return false; }
   // resources first (cheap reject), as upstream does
   for (int r = 0; r < P.R; ++r) {
@@ -746,6 +749,9 @@ KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, u
   }
   return true;
 }
+
+// row of a pod in the per-simulation result arrays
+KG_HD uint32_t pod_row(const SimState& S, uint32_t pod) { return pod < S.n_shared ? pod : pod - S.pod_base + S.n_shared; }
 
 // ------------------------------------------------------------------ one Solve by one workgroup
 // NT = threads in the workgroup.  `sh` lives in LDS.
@@ -809,7 +815,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     }
     KG_SYNC();
   }
-  const uint32_t QCAP = (uint32_t)P.P + 1;
+  const uint32_t QCAP = S.qcap;
   while (true) {
     // ---- Queue.Pop
     KG_FOR_THREADS(tid, NT) {
@@ -871,8 +877,8 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
         if (tid == 0) {
           uint32_t reason = 0;
           eval_node<true>(P, S, sh, sh.best, &reason);
-          S.pod_kind[sh.pod] = 1;
-          S.pod_index[sh.pod] = (int32_t)sh.best;
+          S.pod_kind[pod_row(S, sh.pod)] = 1;
+          S.pod_index[pod_row(S, sh.pod)] = (int32_t)sh.best;
           if (STATS) S.counters[0] += sh.best + 1;
         }
       }
@@ -1203,8 +1209,8 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
           }
           S.c_stamp[c] = ++sh.seq;
           if (fresh) S.c_hstamp[c] = sh.seq;
-          S.pod_kind[sh.pod] = 2;
-          S.pod_index[sh.pod] = (int32_t)c;
+          S.pod_kind[pod_row(S, sh.pod)] = 2;
+          S.pod_index[pod_row(S, sh.pod)] = (int32_t)c;
           row_record_topology(P, S, sh, R);
         }
       }
@@ -1238,9 +1244,9 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     KG_FOR_THREADS(tid, NT) {
       if (tid == 0) {
         const uint32_t pod = sh.pod;
-        S.pod_kind[pod] = 0;
-        S.pod_index[pod] = -1;
-        S.pod_reason[pod] = sh.reason ? sh.reason : 8;
+        S.pod_kind[pod_row(S, pod)] = 0;
+        S.pod_index[pod_row(S, pod)] = -1;
+        S.pod_reason[pod_row(S, pod)] = sh.reason ? sh.reason : 8;
         uint4 qe;
         qe.x = pod;
         sh.qlen += 1;
@@ -1267,6 +1273,89 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
   }
   KG_SYNC();
 #undef KG_T
+}
+
+}  // namespace kg
+
+// ------------------------------------------------------------------ batches of simulations (consolidation)
+namespace kg {
+
+// What the host needs back from one SimulateScheduling to run computeConsolidation's decision logic.
+struct SimResult {
+  uint32_t nclaims;          // new NodeClaims
+  uint32_t errors;           // non-pending pods left unschedulable or placed on a node that is not initialised
+  uint32_t tmpl;             // template (nodepool, weight order) of claim 0
+  uint32_t n_pods;
+  uint32_t zone_meta, ct_meta, zid_meta, pad;
+  uint64_t zone_word, ct_word, zid_word;
+  uint64_t mask[KG_TWLDS];   // option mask of claim 0 (<= 1024 types)
+};
+
+struct SimBatch {
+  uint8_t* arena;            // (nsims + 1) slots of `stride` bytes; slot 0 holds the pristine state image
+  unsigned long long stride;
+  unsigned long long o_queue, o_excl, o_remaining;
+  const uint32_t* q_off;     // [nsims + 1] -> q_ent
+  const uint4* q_ent;        // initial queue entries {pod, variant, 0, 0} of every simulation, each in Queue order
+  const uint32_t* x_off;     // [nsims + 1] -> x_node
+  const uint32_t* x_node;    // scan positions of the candidate nodes of every simulation
+  const int64_t* rem_adj;    // [nsims][R * NP] limits given back by the candidates (null when no NodePool has limits)
+  uint32_t* nqueue;          // [nsims]
+  SimResult* results;        // [nsims]
+  const uint8_t* pod_nonpending;  // [P] 1 = bound pod being rescheduled (must schedule), 0 = pending pod
+  const uint64_t* node_uninit;    // [NW] nodes that are not initialised
+  int nsims;
+};
+
+// slot i+1 <- pristine image, then the simulation's queue, candidate exclusion mask and limits
+KG_HD void sim_init_copy(const SimBatch& B, uint32_t i, uint32_t tid, uint32_t nthreads) {
+  const uint64_t* src = (const uint64_t*)B.arena;
+  uint64_t* dst = (uint64_t*)(B.arena + (size_t)(i + 1) * B.stride);
+  for (size_t k = tid; k < B.stride / 8; k += nthreads) dst[k] = src[k];
+}
+KG_HD void sim_init_patch(const DevProblem& P, const SimBatch& B, uint32_t i, uint32_t tid, uint32_t nthreads) {
+  uint8_t* slot = B.arena + (size_t)(i + 1) * B.stride;
+  uint4* q = (uint4*)(slot + B.o_queue);
+  const uint32_t q0 = B.q_off[i], qn = B.q_off[i + 1] - q0;
+  for (uint32_t k = tid; k < qn; k += nthreads) q[k] = B.q_ent[q0 + k];
+  if (tid == 0) {
+    B.nqueue[i] = qn;
+    uint64_t* excl = (uint64_t*)(slot + B.o_excl);
+    for (uint32_t k = B.x_off[i]; k < B.x_off[i + 1]; ++k) excl[B.x_node[k] >> 6] |= 1ull << (B.x_node[k] & 63);
+    if (B.rem_adj) {
+      int64_t* rem = (int64_t*)(slot + B.o_remaining);
+      for (int k = 0; k < P.R * P.NP; ++k) if (rem[k] != 0x7FFFFFFFFFFFFFFFll) rem[k] += B.rem_adj[(size_t)i * P.R * P.NP + k];
+    }
+  }
+}
+
+// compact result of simulation i (one thread)
+KG_HD void sim_gather(const DevProblem& P, const SimBatch& B, const SimState& S, uint32_t i) {
+  SimResult r;
+  r.nclaims = S.header[0];
+  r.errors = 0;
+  for (uint32_t k = B.q_off[i]; k < B.q_off[i + 1]; ++k) {
+    const uint32_t pod = B.q_ent[k].x;
+    if (!B.pod_nonpending[pod]) continue;
+    const uint32_t row = pod_row(S, pod);
+    const uint8_t kind = S.pod_kind[row];
+    if (kind == 0) r.errors++;
+    else if (kind == 1) {
+      const uint32_t n = (uint32_t)S.pod_index[row];
+      if ((B.node_uninit[n >> 6] >> (n & 63)) & 1) r.errors++;
+    }
+  }
+  r.tmpl = 0; r.n_pods = 0; r.zone_meta = r.ct_meta = r.zid_meta = 0; r.pad = 0; r.zone_word = r.ct_word = r.zid_word = 0;
+  for (int w = 0; w < KG_TWLDS; ++w) r.mask[w] = 0;
+  if (r.nclaims == 1) {
+    r.tmpl = S.c_tmpl[0];
+    r.n_pods = S.c_npods[0];
+    for (int w = 0; w < P.TW && w < KG_TWLDS; ++w) r.mask[w] = S.c_mask[(size_t)w * P.Cmax];
+    if (P.slot_zone >= 0) { const int a = P.spec_slot[P.slot_zone]; r.zone_meta = S.c_meta[(size_t)a * P.Cmax]; r.zone_word = S.c_bits[(size_t)P.aoff[a] * P.Cmax]; }
+    if (P.slot_ct >= 0) { const int a = P.spec_slot[P.slot_ct]; r.ct_meta = S.c_meta[(size_t)a * P.Cmax]; r.ct_word = S.c_bits[(size_t)P.aoff[a] * P.Cmax]; }
+    if (P.slot_zid >= 0) { const int a = P.spec_slot[P.slot_zid]; r.zid_meta = S.c_meta[(size_t)a * P.Cmax]; r.zid_word = S.c_bits[(size_t)P.aoff[a] * P.Cmax]; }
+  }
+  B.results[i] = r;
 }
 
 }  // namespace kg

@@ -39,6 +39,10 @@ class Library:
         d.kg_cluster_free.argtypes = [C.c_void_p]
         d.kg_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         d.kg_backend.restype = C.c_char_p
+        for fn in (d.kg_consolidate_single, d.kg_consolidate_multi):
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                           C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+        d.kg_consolidate_select.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         d.kg_set_collect_stats.argtypes = [C.c_void_p, C.c_int32]
         self.ctx = C.c_void_p()
         st = d.kg_init(device, C.byref(self.ctx))
@@ -74,6 +78,23 @@ class Library:
         self._check(self.dll.kg_solve(self.ctx, arr, len(catalogs), cluster, C.addressof(pods.desc), C.addressof(nodepools.desc),
                                       C.addressof(rb.res)))
         return rb
+
+    def consolidate_records(self, catalogs, cluster, pending, nodepools, cands, multi):
+        """One SimulateScheduling + computeConsolidation per unit of the shard -> (records, device_ms)."""
+        import numpy as np
+        arr = (C.c_void_p * len(catalogs))(*catalogs)
+        recs = np.zeros(max(cands.desc.n_candidates, 1), abi.CANDIDATE_RECORD)
+        k, ms = C.c_uint32(0), C.c_double(0)
+        fn = self.dll.kg_consolidate_multi if multi else self.dll.kg_consolidate_single
+        self._check(fn(self.ctx, arr, len(catalogs), cluster, C.addressof(pending.desc), C.addressof(nodepools.desc), C.addressof(cands.desc),
+                       recs.ctypes.data, recs.shape[0], C.byref(k), C.byref(ms)))
+        return recs[:k.value], ms.value
+
+    def consolidate_select(self, catalog, records, n_candidates, multi, cap_types=1024):
+        db = abi.DecisionBuffer(cap_types)
+        self._check(self.dll.kg_consolidate_select(self.ctx, catalog, 1 if multi else 0, records.ctypes.data if len(records) else None,
+                                                   len(records), n_candidates, C.addressof(db.dec)))
+        return db.decode()
 
     def close(self):
         if self.ctx:

@@ -267,3 +267,44 @@ def disruption_order(nodes, bound):
         c = 1.0 + p.get("deletion_cost", 0) / float(2 ** 27) + p.get("priority", 0) / float(2 ** 25)
         cost[p["node"]] += max(-10.0, min(10.0, c))
     return sorted(range(len(nodes)), key=lambda i: cost[i])
+
+
+def dense_cluster(n_nodes, seed, types, zones, nodepool="default", lo=0.3, hi=0.95):
+    """Consolidation test cluster with a spread of utilisations: node i is filled with 250m-4 CPU pods up to a target
+    drawn uniformly from [lo, hi] of its allocatable cpu, so single-node simulations end in all three verdicts
+    (pods fit elsewhere -> delete; a cheaper type fits them -> replace; neither -> no-op)."""
+    r = SplitMix64(seed)
+    fams = {"m5", "c5", "r5", "m6i", "c6i", "r6i", "m6g", "c6g"}
+    sizes = {"large", "xlarge", "2xlarge", "4xlarge"}
+    pool = [t for t in types if t["name"].split(".")[0] in fams and t["name"].split(".")[1] in sizes]
+    nodes, bound = [], []
+    for i in range(n_nodes):
+        t = pool[r.below(len(pool))]
+        zone = zones[r.below(len(zones))]
+        ct = "spot" if r.below(2) == 0 else "on-demand"
+        labels = {k: vals[0] for k, op, vals in t["requirements"] if op == "In" and len(vals) == 1}
+        name = "node-%05d" % i
+        labels.update({L_ZONE: zone, L_CT: ct, L_NODEPOOL: nodepool, L_HOSTNAME: name})
+        alloc = {k: v - t["overhead"].get(k, 0) for k, v in t["capacity"].items()}
+        target = int(alloc["cpu"] * (lo + (hi - lo) * r.uniform()))
+        used = {"cpu": 0, "memory": 0, "pods": 0}
+        k = 0
+        while used["cpu"] < target and k < 60:
+            cpu = [250, 500, 1000, 2000, 4000][r.below(5)]
+            mem = cpu * [1, 2, 4][r.below(3)] * GI
+            if used["cpu"] + cpu > alloc["cpu"] or used["memory"] + mem > alloc["memory"] or used["pods"] + 1000 > alloc["pods"]:
+                k += 1
+                if cpu == 250:
+                    break
+                continue
+            used["cpu"] += cpu
+            used["memory"] += mem
+            used["pods"] += 1000
+            bound.append({"uid": "%s-p%02d" % (name, k), "ns": "default", "creation_ts": 1690000000 + i,
+                          "labels": {"app": "svc-%02d" % r.below(40)}, "requests": {"cpu": cpu, "memory": mem},
+                          "node": i, "reschedulable": True, "priority": int(r.below(3)) * 1000})
+            k += 1
+        avail = {kk: v - used.get(kk, 0) for kk, v in alloc.items()}
+        nodes.append({"name": name, "labels": labels, "taints": [], "available": avail, "capacity": dict(t["capacity"]),
+                      "daemon_requests": {}, "initialized": True, "managed": True, "deleting": False})
+    return nodes, bound

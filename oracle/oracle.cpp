@@ -1261,6 +1261,207 @@ static void fillCounters(const SchedCtx& C, kg_results* out) {
   out->algorithmic_bytes = 212.0 * C.cnt.visited_existing + 400.0 * (C.cnt.visited_claims + C.cnt.new_claim_scans) + 336.0 * C.cnt.visited_claim_types;
 }
 
+
+// ------------------------------------------------------------------ disruption / consolidation (Appendix A.9)
+// Offerings.WorstLaunchPrice over the AVAILABLE offerings: spot is preferred at launch, so the worst price is the
+// most expensive compatible spot offering when the requirements allow spot, else the most expensive on-demand one.
+static double worstLaunchPrice(const InstanceType* it, const Requirements& reqs, const SchedCtx& C) {
+  const Requirement ct = reqs.Get(C.keyCT);
+  for (int want : {C.valSpot, C.valOnDemand}) {
+    if (!ct.Has(want)) continue;
+    bool any = false;
+    double worst = 0;
+    for (auto& o : it->offerings) {
+      if (!o.available || o.ct != want || !offeringCompatible(reqs, o, C)) continue;
+      if (!any || o.price > worst) { worst = o.price; any = true; }
+    }
+    if (any) return worst;
+  }
+  return std::numeric_limits<double>::max();
+}
+
+// NodeClaim.RemoveInstanceTypeOptionsByPriceAndMinValues; false = minValues no longer satisfiable
+static bool removeByPriceAndMinValues(vector<InstanceType*>* options, const Requirements& reqs, double maxPrice, const SchedCtx& C) {
+  vector<InstanceType*> kept;
+  for (auto* it : *options) if (worstLaunchPrice(it, reqs, C) < maxPrice) kept.push_back(it);
+  *options = std::move(kept);
+  int n;
+  return SatisfiesMinValues(*options, reqs, &n);
+}
+
+struct Outcome {
+  int decision = KG_DECISION_NOOP;
+  int nodepool = 0;
+  vector<InstanceType*> options;  // price ordered
+  Requirements reqs;
+  double candidatePrice = 0;
+  bool spotOnly = false;
+};
+
+static const int kMinTypesSpotToSpot = 15;  // MinInstanceTypesForSpotToSpotConsolidation
+
+// candidate price: cheapest offering of the node's instance type compatible with the node's labels
+static bool candidatePrice(Problem& pr, int node, double* price) {
+  SchedCtx& C = pr.C;
+  auto& cn = pr.nodes[node];
+  auto itl = cn.labels.find(C.keyInstanceType);
+  if (itl == cn.labels.end()) return false;
+  const InstanceType* ty = nullptr;
+  for (auto& cat : pr.catalogs)
+    for (auto& t : cat->types) if (t->name == itl->second) { ty = t.get(); break; }
+  if (!ty) return false;
+  vector<std::pair<int, int>> ls(cn.labels.begin(), cn.labels.end());
+  Requirements nodeReqs = NewLabelRequirements(ls);
+  bool any = false;
+  double best = 0;
+  for (auto& o : ty->offerings) {
+    if (!offeringCompatible(nodeReqs, o, C)) continue;
+    if (!any || o.price < best) { best = o.price; any = true; }
+  }
+  if (!any) return false;
+  *price = best;
+  return true;
+}
+
+// disruption.SimulateScheduling + consolidation.computeConsolidation for one set of candidate nodes
+static Outcome computeConsolidation(Problem& pr, const vector<int>& cands, bool spotToSpotEnabled, uint64_t* sims) {
+  SchedCtx& C = pr.C;
+  Outcome out;
+  (*sims)++;
+  std::set<int> excluded(cands.begin(), cands.end());
+  vector<Pod*> pods;
+  std::set<const Pod*> nonPending;
+  for (auto& p : pr.pending) pods.push_back(p.get());
+  for (size_t i = 0; i < pr.nodes.size(); ++i)
+    if (pr.nodes[i].deleting && !excluded.count((int)i))
+      for (Pod* bp : pr.nodes[i].pods) if (bp->reschedulable) { pods.push_back(bp); nonPending.insert(bp); }
+  for (int n : cands)
+    for (Pod* bp : pr.nodes[n].pods) if (bp->reschedulable) { pods.push_back(bp); nonPending.insert(bp); }
+  // each simulation relaxes its own copies of the pods
+  vector<std::unique_ptr<Pod>> copies;
+  vector<Pod*> work;
+  std::map<const Pod*, const Pod*> origin;
+  for (Pod* p : pods) { copies.push_back(std::make_unique<Pod>(*p)); work.push_back(copies.back().get()); origin[copies.back().get()] = p; }
+  auto s = newScheduler(pr, work, excluded);
+  std::map<const Pod*, uint32_t> errs;
+  s->Solve(work, &errs);
+  vector<uint8_t> truncFailed;
+  truncateAll(*s, pr.maxInstanceTypes, &truncFailed, &errs);
+  // pods that would land on a node that is not initialised yet count as errors
+  for (auto& n : s->existingNodes) if (!n->initialized) for (Pod* p : n->pods) errs[p] = KG_REASON_UNINITIALIZED_NODE;
+  for (auto& kv : errs) if (nonPending.count(origin[kv.first])) return out;  // !AllNonPendingPodsScheduled
+  vector<NodeClaim*> claims;
+  for (size_t i = 0; i < s->newNodeClaims.size(); ++i) if (!truncFailed[i]) claims.push_back(s->newNodeClaims[i].get());
+  if (claims.empty()) { out.decision = KG_DECISION_DELETE; return out; }
+  if (claims.size() != 1) return out;
+  double price = 0;
+  bool allSpot = true;
+  for (int n : cands) {
+    double p;
+    if (!candidatePrice(pr, n, &p)) return out;
+    price += p;
+    auto ct = pr.nodes[n].labels.find(C.keyCT);
+    if (ct == pr.nodes[n].labels.end() || ct->second != C.valSpot) allSpot = false;
+  }
+  NodeClaim& nc = *claims[0];
+  out.candidatePrice = price;
+  out.nodepool = nc.pool->index;
+  out.reqs = nc.requirements;
+  out.options = OrderByPrice(nc.options, out.reqs, C);
+  const Requirement ct = out.reqs.Get(C.keyCT);
+  if (allSpot && ct.Has(C.valSpot)) {
+    // computeSpotToSpotConsolidation
+    if (!spotToSpotEnabled) return out;
+    out.reqs.Add(Requirement::New(C.keyCT, In, {C.valSpot}));
+    vector<InstanceType*> compat;
+    for (auto* it : out.options) {
+      bool ok = false;
+      for (auto& o : it->offerings) if (o.available && offeringCompatible(out.reqs, o, C)) { ok = true; break; }
+      if (ok) compat.push_back(it);
+    }
+    out.options = std::move(compat);
+    if (!removeByPriceAndMinValues(&out.options, out.reqs, price, C) || out.options.empty()) { out.options.clear(); return out; }
+    out.spotOnly = true;
+    if (cands.size() > 1) { out.decision = KG_DECISION_REPLACE; return out; }
+    if ((int)out.options.size() < kMinTypesSpotToSpot) { out.options.clear(); return out; }
+    int keep = kMinTypesSpotToSpot;
+    if (out.reqs.HasMinValues()) {
+      int need = 0;
+      SatisfiesMinValues(out.options, out.reqs, &need);
+      keep = std::max(keep, need);
+    }
+    if ((int)out.options.size() > keep) out.options.resize(keep);
+    out.decision = KG_DECISION_REPLACE;
+    return out;
+  }
+  if (!removeByPriceAndMinValues(&out.options, out.reqs, price, C) || out.options.empty()) { out.options.clear(); return out; }
+  // OD -> [OD, spot]: the price filter assumed the spot variant launches; pin the replacement to spot
+  if (ct.Has(C.valSpot) && ct.Has(C.valOnDemand)) { out.reqs.Add(Requirement::New(C.keyCT, In, {C.valSpot})); out.spotOnly = true; }
+  out.decision = KG_DECISION_REPLACE;
+  return out;
+}
+
+// multi-node: filterOutSameType -- a replacement must be cheaper than the cheapest candidate of a type it may launch
+static void filterOutSameType(Problem& pr, Outcome* o, const vector<int>& cands) {
+  SchedCtx& C = pr.C;
+  std::map<int, double> priceByType;
+  for (int n : cands) {
+    double p;
+    auto itl = pr.nodes[n].labels.find(C.keyInstanceType);
+    if (itl == pr.nodes[n].labels.end() || !candidatePrice(pr, n, &p)) continue;
+    auto f = priceByType.find(itl->second);
+    if (f == priceByType.end() || p < f->second) priceByType[itl->second] = p;
+  }
+  double maxPrice = std::numeric_limits<double>::max();
+  for (auto* it : o->options) {
+    auto f = priceByType.find(it->name);
+    if (f != priceByType.end() && f->second < maxPrice) maxPrice = f->second;
+  }
+  removeByPriceAndMinValues(&o->options, o->reqs, maxPrice, C);  // minValues error swallowed upstream
+}
+
+static Outcome evaluateUnit(Problem& pr, const kg_candidates_desc* cd, bool multi, uint32_t unit, uint64_t* sims) {
+  vector<int> cands;
+  if (multi) for (uint32_t i = 0; i <= unit; ++i) cands.push_back(cd->candidates[i]);
+  else cands.push_back(cd->candidates[unit]);
+  if (!multi && pr.nodes[cands[0]].pods.empty()) return Outcome();  // (empty nodes belong to emptiness; skipped)
+  if (!multi) {
+    bool any = false;
+    for (Pod* p : pr.nodes[cands[0]].pods) any |= p->reschedulable;
+    if (!any) return Outcome();
+  }
+  Outcome o = computeConsolidation(pr, cands, cd->spot_to_spot_enabled != 0, sims);
+  if (multi && o.decision == KG_DECISION_REPLACE) {
+    filterOutSameType(pr, &o, cands);
+    if (o.options.empty()) o.decision = KG_DECISION_NOOP;
+  }
+  return o;
+}
+
+static void fillRecord(const Outcome& o, int unit, kg_candidate_record* r) {
+  std::memset(r, 0, sizeof *r);
+  r->candidate = unit;
+  r->decision = o.decision;
+  if (o.decision != KG_DECISION_REPLACE) return;
+  r->nodepool = (uint32_t)o.nodepool;
+  r->n_types = (uint32_t)o.options.size();
+  r->candidate_price = o.candidatePrice;
+  r->spot_only = o.spotOnly;
+  for (auto* it : o.options) if (it->index < 13 * 64) r->type_mask[it->index >> 6] |= 1ull << (it->index & 63);
+}
+static void fillDecision(const Outcome& o, int nCands, int first, uint64_t sims, kg_decision* d) {
+  d->decision = o.decision;
+  d->n_candidates = o.decision == KG_DECISION_NOOP ? 0 : nCands;
+  d->first_candidate = o.decision == KG_DECISION_NOOP ? -1 : first;
+  d->nodepool = (uint32_t)o.nodepool;
+  d->n_types = 0;
+  d->replacement_spot_only = o.spotOnly;
+  d->candidate_price = o.decision == KG_DECISION_REPLACE ? o.candidatePrice : 0;
+  d->simulations = sims;
+  if (o.decision == KG_DECISION_REPLACE)
+    for (auto* it : o.options) { if (d->n_types < d->cap_type_ids && d->type_ids) d->type_ids[d->n_types] = (uint32_t)it->index; d->n_types++; }
+}
+
 }  // namespace ko
 
 using namespace ko;
@@ -1315,6 +1516,74 @@ int32_t ko_solve(const kg_catalog_desc* const* catalogs, uint32_t n_catalogs, co
     return W.overflow ? KG_ENOMEM : KG_OK;
   } catch (const std::exception& e) {
     fprintf(stderr, "ko_solve: %s\n", e.what());
+    return KG_EINVAL;
+  }
+}
+
+// computeConsolidation for every unit of this shard (same records as kg_consolidate_single / _multi)
+int32_t ko_consolidate_records(const kg_catalog_desc* const* catalogs, uint32_t n_catalogs, const kg_cluster_desc* cluster,
+                               const kg_pods_desc* pending, const kg_nodepools_desc* nodepools, const kg_candidates_desc* cands, int32_t multi,
+                               kg_candidate_record* records, uint32_t cap_records, uint32_t* n_records, double* ms) {
+  try {
+    auto pr = buildProblem(catalogs, n_catalogs, cluster, pending, nodepools);
+    auto t0 = std::chrono::steady_clock::now();
+    const uint32_t n = cands->n_candidates;
+    const uint32_t lo = multi ? 1 : 0, hi = multi ? std::min<uint32_t>(n, 100) : n;  // multi: mid in [1, min(n,100)-1]
+    const int shards = std::max(cands->n_shards, 1);
+    uint32_t k = 0;
+    uint64_t sims = 0;
+    for (uint32_t u = lo; u < hi; ++u) {
+      if ((int)((u - lo) % shards) != cands->shard) continue;
+      Outcome o = evaluateUnit(*pr, cands, multi != 0, u, &sims);
+      if (k < cap_records) fillRecord(o, (int)u, &records[k]);
+      k++;
+    }
+    *n_records = k;
+    if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return k > cap_records ? KG_ENOMEM : KG_OK;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "ko_consolidate_records: %s\n", e.what());
+    return KG_EINVAL;
+  }
+}
+
+// The reference's sequential algorithms: SingleNodeConsolidation.ComputeCommand (first candidate in order with a valid
+// command) and MultiNodeConsolidation.firstNConsolidationOption (binary search over prefixes of at most 100 candidates).
+int32_t ko_consolidate_decide(const kg_catalog_desc* const* catalogs, uint32_t n_catalogs, const kg_cluster_desc* cluster,
+                              const kg_pods_desc* pending, const kg_nodepools_desc* nodepools, const kg_candidates_desc* cands, int32_t multi,
+                              kg_decision* out) {
+  try {
+    auto pr = buildProblem(catalogs, n_catalogs, cluster, pending, nodepools);
+    auto t0 = std::chrono::steady_clock::now();
+    uint64_t sims = 0;
+    Outcome none;
+    const uint32_t n = cands->n_candidates;
+    if (!multi) {
+      bool done = false;
+      for (uint32_t u = 0; u < n && !done; ++u) {
+        Outcome o = evaluateUnit(*pr, cands, false, u, &sims);
+        if (o.decision == KG_DECISION_NOOP) continue;
+        fillDecision(o, 1, (int)u, sims, out);
+        done = true;
+      }
+      if (!done) fillDecision(none, 0, -1, sims, out);
+    } else {
+      Outcome last;
+      int lastN = 0;
+      if (n >= 2) {
+        int mn = 1, mx = (int)std::min<uint32_t>(n, 100) - 1;
+        while (mn <= mx) {
+          const int mid = (mn + mx) / 2;
+          Outcome o = evaluateUnit(*pr, cands, true, (uint32_t)mid, &sims);
+          if (o.decision != KG_DECISION_NOOP) { last = o; lastN = mid + 1; mn = mid + 1; } else mx = mid - 1;
+        }
+      }
+      fillDecision(last, lastN, 0, sims, out);
+    }
+    out->device_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return KG_OK;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "ko_consolidate_decide: %s\n", e.what());
     return KG_EINVAL;
   }
 }

@@ -1,0 +1,60 @@
+"""Consolidation parity plumbing shared by the emulation (CPU) and GPU tests: kg_consolidate_single / _multi records and
+kg_consolidate_select decisions against the oracle's computeConsolidation per unit and its sequential selection."""
+import numpy as np
+
+from karpenter_amd import abi, workloads as wl
+from oracle import loader
+from tests.helpers import catalog776, families
+
+
+def cluster(name, n):
+    zones, types = catalog776()
+    if name == "dense":
+        nodes, bound = wl.dense_cluster(n, 11, types, zones, lo=0.7, hi=0.99)
+        return types, nodes, bound, []
+    if name == "sparse":
+        nodes, bound = wl.existing_cluster(n, 11, types, zones)
+        return types, nodes, bound, []
+    if name == "dense_pending":
+        nodes, bound = wl.dense_cluster(n, 5, types, zones, lo=0.8, hi=0.99)
+        return types, nodes, bound, wl.mixed_pods(6, 9, zones, families(types))
+    if name == "uninitialized":
+        nodes, bound = wl.dense_cluster(n, 3, types, zones, lo=0.5, hi=0.9)
+        for i, nd in enumerate(nodes):
+            if i % 3 == 0:
+                nd["initialized"] = False
+        return types, nodes, bound, []
+    raise KeyError(name)
+
+
+def check_consolidation(L, name, n, spot_to_spot, n_shards=3):
+    types, nodes, bound, pending = cluster(name, n)
+    order = wl.disruption_order(nodes, bound)
+    cat, cl = abi.build_catalog(types), abi.build_cluster(nodes, bound)
+    pend, nps = abi.build_pods(pending), abi.build_nodepools([wl.default_nodepool()], wl.WELL_KNOWN_LABELS)
+    hcat, hcl = L.catalog_upload(cat), L.cluster_upload(cl)
+    seen = set()
+    try:
+        for multi in (False, True):
+            cd = abi.build_candidates(order, spot_to_spot=spot_to_spot)
+            st, ro, _ = loader.consolidate_records([cat], cl, pend, nps, cd, multi)
+            assert st == 0
+            rg, _ = L.consolidate_records([hcat], hcl, pend, nps, cd, multi)
+            a, b = [abi.record_tuple(r) for r in ro], [abi.record_tuple(r) for r in rg]
+            assert len(a) == len(b)
+            for x, y in zip(a, b):
+                assert x == y, (name, multi, x, y)
+            seen.update(x[1] for x in a)
+            # the shards' records, gathered, give the reference's sequential decision
+            parts = [L.consolidate_records([hcat], hcl, pend, nps, abi.build_candidates(order, spot_to_spot=spot_to_spot, shard=s, n_shards=n_shards), multi)[0]
+                     for s in range(n_shards)]
+            assert sum(len(p) for p in parts) == len(a)
+            dg = L.consolidate_select(hcat, np.concatenate(parts), len(order), multi)
+            st, do = loader.consolidate_decide([cat], cl, pend, nps, cd, multi)
+            assert st == 0
+            for k in ("decision", "n_candidates", "first_candidate", "nodepool", "types", "spot_only", "candidate_price"):
+                assert do[k] == dg[k], (name, multi, k, do[k], dg[k])
+    finally:
+        L.dll.kg_cluster_free(hcl)
+        L.dll.kg_catalog_free(hcat)
+    return seen

@@ -1,0 +1,25 @@
+"""Consolidation through the TEST-ONLY emulation build (host compile + simulation batching + decision logic on CPU)."""
+import os
+
+import pytest
+
+from karpenter_amd import lib
+from tests.cons_common import check_consolidation
+from tests.helpers import EMU_PATH
+
+pytestmark = pytest.mark.skipif(not os.path.exists(EMU_PATH), reason="emulation build missing: run __graft_entry__.build()")
+
+
+@pytest.fixture(scope="module")
+def L():
+    l = lib.Library(EMU_PATH)
+    yield l
+    l.close()
+
+
+@pytest.mark.parametrize("name,n,s2s", [("dense", 120, False), ("dense", 120, True), ("sparse", 60, False), ("dense_pending", 80, True),
+                                         ("uninitialized", 60, False)])
+def test_consolidation(L, name, n, s2s):
+    seen = check_consolidation(L, name, n, s2s)
+    if name == "dense":
+        assert seen == {0, 1, 2}  # no-op, delete and replace all occur

@@ -1,0 +1,21 @@
+"""GPU parity: kg_consolidate_single / _multi / _select through the C ABI of libkarpgpu.so vs the CPU oracle."""
+import pytest
+
+from karpenter_amd import lib
+from tests.cons_common import check_consolidation
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    l = lib.Library()
+    assert l.backend() == "hip-gfx950"
+    yield l
+    l.close()
+
+
+@pytest.mark.parametrize("name,n,s2s", [("dense", 150, False), ("dense", 150, True), ("sparse", 100, False), ("dense_pending", 120, True),
+                                         ("uninitialized", 90, False), ("dense", 400, True)])
+def test_consolidation(L, name, n, s2s):
+    check_consolidation(L, name, n, s2s)
