@@ -9,6 +9,12 @@ result download / price-ordered truncation, i.e. everything between handing over
 NodeClaims.  Solve does not shard (FFD is one chain of dependent placements): with N ranks each rank runs an
 independent replica of the batch ("replicas only", weak scaling, no data-path collective).
 
+The second half of the metric, consolidation candidates/sec (config C4: 5000-node cluster, single-node = one
+SimulateScheduling per candidate, multi-node = one per prefix of the first 100), DOES shard: units are dealt round-robin
+over the ranks, each rank runs its simulations with no data-path collective, and one all-gather of the fixed-size
+records (RCCL) feeds the reference's selection.  It is reported in the `consolidation` object of the same line
+(strong scaling: the whole job is the same 5000 candidates at every N).
+
 Prints ONE JSON line on rank 0 with `roofline` (k_solve: algorithmic bytes of SURVEY.md 8(d) / HIP-event kernel
 time) and `cpu_baseline` (the CPU oracle, one thread, same batch).
 """
@@ -25,6 +31,50 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
+def bench_consolidation(args, L, hcat, types, zones, world, rank, barrier, dist, torch):
+    """C4: consolidation on a synthetic cluster (seed 11), single- and multi-node, units sharded over the ranks."""
+    from karpenter_amd import abi, distributed, workloads as wl
+    nodes, bound = wl.existing_cluster(args.nodes, 11, types, zones)
+    order = wl.disruption_order(nodes, bound)
+    cl = abi.build_cluster(nodes, bound)
+    pend, nps = abi.build_pods([]), abi.build_nodepools([wl.default_nodepool()], wl.WELL_KNOWN_LABELS)
+    hcl = L.cluster_upload(cl)
+    device = "cuda" if world > 1 else "cpu"
+    out = {"workload": "C4: %d-node cluster (seed 11, ~12 pods/node, 35%% utilisation), %d bound pods, 0 pending" % (len(nodes), len(bound)),
+           "scaling": "strong", "collective": "all_gather of %d-byte kg_candidate_record rows" % abi.CANDIDATE_RECORD.itemsize}
+    for multi in (False, True):
+        for _ in range(args.warmup):
+            distributed.consolidate(L, hcat, hcl, pend, nps, order, multi, device=device)
+        barrier()
+        t0 = time.perf_counter()
+        dms = []
+        for _ in range(args.steps):
+            dec, n_local, ms = distributed.consolidate(L, hcat, hcl, pend, nps, order, multi, device=device)
+            dms.append(ms)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        units = (min(len(order), 100) - 1) if multi else len(order)
+        out["multi_node" if multi else "single_node"] = {
+            "value": units * args.steps / dt, "unit": "prefixes/s" if multi else "candidates/s", "units_per_round": units,
+            "ms_per_round": dt * 1e3 / args.steps, "device_ms_per_round_rank0": sum(dms) / len(dms),
+            "decision": {k: dec[k] for k in ("decision", "n_candidates", "first_candidate")}}
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import loader
+        k = min(30, len(order))
+        cat = abi.build_catalog(types)
+        c0 = time.perf_counter()
+        st, ro, _ = loader.consolidate_records([cat], cl, pend, nps, abi.build_candidates(order[:k]), False)
+        ct = time.perf_counter() - c0
+        out["cpu_baseline"] = {"value": k / ct, "unit": "candidates/s", "cores": 1, "kind": "port",
+                               "sample": "the first %d candidates of the same cluster, one oracle SimulateScheduling + computeConsolidation each" % k}
+    L.dll.kg_cluster_free(hcl)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -32,6 +82,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pods", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nodes", type=int, default=5000, help="C4 cluster size")
+    ap.add_argument("--no-consolidation", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -82,13 +134,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    cons = None
+    if not args.no_consolidation:
+        cons = bench_consolidation(args, L, hcat, types, zones, world, rank, barrier, dist, torch)
+
     if rank == 0:
         ms_per_step = dt * 1000.0 / args.steps
         value = args.pods * world * args.steps / dt
         k_ms = sum(solve_ms) / len(solve_ms)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         out = {
-            "metric": "pods/sec in Solve (10k pods x 750 types)", "value": value, "unit": "pods/s", "n_gpus": world,
+            "metric": "pods/sec in Solve (10k pods x 750 types) + consolidation candidates/sec", "value": value, "unit": "pods/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "config": {"workload": "C2: %d mixed cpu/mem/gpu pods with arch/zone/instance-family/generation constraints x 776 types x 3 zones x spot+on-demand, 1 NodePool, seed 42"
@@ -101,6 +157,8 @@ def main():
                          "note": "rows the reference algorithm visits up to its first feasible index (SURVEY.md 8d): "
                                  "212 B/existing node, 400 B/NodeClaim, 336 B/instance type"},
         }
+        if cons is not None:
+            out["consolidation"] = cons
         if not args.no_cpu_baseline:
             # CPU oracle (oracle/oracle.cpp, -O2, one thread) on the same batch: 3 full Solves of the workload
             times = []
