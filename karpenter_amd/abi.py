@@ -451,3 +451,108 @@ def record_tuple(r):
     """The comparable part of a kg_candidate_record (zone_mask / ct_mask are library-internal)."""
     return (int(r["candidate"]), int(r["decision"]), int(r["nodepool"]), int(r["n_types"]), float(r["candidate_price"]),
             tuple(int(x) for x in r["type_mask"]), int(r["spot_only"]))
+
+
+def build_launch(requirements, requests):
+    """A NodeClaim's launch inputs: (Pools, requirements range, requests range) for kg_launch_filter / kg_truncate."""
+    pb = _PoolBuilder()
+    pb.s("nodeclaim")
+    rr = pb.req_list(requirements)
+    qq = pb.quantity_list(requests)
+    pools = pb.finish()
+    return Built(pools, [pb]), Range(*rr), Range(*qq)
+
+
+AMI_FAMILIES = {"AL2": 0, "AL2023": 1, "Bottlerocket": 2, "Ubuntu": 3, "Windows2019": 4, "Windows2022": 5, "Custom": 6}
+AWS_TO_KUBE_ARCH = {"x86_64": "amd64", "arm64": "arm64"}
+
+
+def build_ec2_catalog(infos, ctx, limits, bandwidth, offering_zones):
+    """Raw EC2 facts (ec2.InstanceTypeInfo-shaped dicts) + provider state -> kg_ec2_catalog_desc for kg_catalog_build_ec2.
+    Pure data marshalling: every derived number is computed by the library."""
+    pb = _PoolBuilder()
+    rows, devs = [], []
+
+    def dev_range(items, mem_key):
+        b = len(devs)
+        for g in items:
+            devs.append((pb.s(g["Name"]), pb.s(g["Manufacturer"]), int(g["Count"]), int((g.get(mem_key) or {}).get("SizeInMiB", 0)) if mem_key else 0))
+        return (b, len(devs) - b)
+
+    for info in infos:
+        name = info["InstanceType"]
+        archs = info["ProcessorInfo"]["SupportedArchitectures"]
+        arch = next((AWS_TO_KUBE_ARCH[a] for a in archs if a in AWS_TO_KUBE_ARCH), "[" + " ".join(archs) + "]")
+        ni = info.get("NetworkInfo") or {}
+        cards = ni.get("NetworkCards") or [{"MaximumNetworkInterfaces": 0}]
+        card = cards[ni.get("DefaultNetworkCardIndex", 0)]
+        st = info.get("InstanceStorageInfo")
+        ebs = info.get("EbsInfo")
+        lim = limits.get(name)
+        man = info["ProcessorInfo"].get("Manufacturer")
+        efa = (ni.get("EfaInfo") or {}).get("MaximumEfaInterfaces") or 0
+        rows.append((
+            pb.s(name), pb.s(arch), 1 if archs and archs[0] == "arm64" else 0, pb.s(info.get("Hypervisor") or None) if info.get("Hypervisor") else KG_NONE,
+            pb.s(man) if man is not None else KG_NONE, int(info["VCpuInfo"]["DefaultVCpus"]), int(info["MemoryInfo"]["SizeInMiB"]),
+            1 if ni.get("EncryptionInTransitSupported") else 0,
+            int(ebs["EbsOptimizedInfo"]["MaximumBandwidthInMbps"]) if ebs is not None and ebs.get("EbsOptimizedSupport") == "default" else -1,
+            int(bandwidth[name]) if name in bandwidth else -1,
+            int(st.get("TotalSizeInGB") or 0) if st is not None and st.get("NvmeSupport") != "unsupported" else -1,
+            int(st["TotalSizeInGB"]) if st is not None and st.get("TotalSizeInGB") is not None else -1,
+            dev_range((info.get("GpuInfo") or {}).get("Gpus") or [], "MemoryInfo"),
+            dev_range((info.get("InferenceAcceleratorInfo") or {}).get("Accelerators") or [], None),
+            int(efa), int(card["MaximumNetworkInterfaces"]), int(ni.get("Ipv4AddressesPerInterface", 0)),
+            1 if lim else 0, 1 if lim and lim["trunking"] else 0, int(lim["branch_interface"]) if lim else 0, int(lim["ipv4_per_interface"]) if lim else 0,
+            pb.values(info.get("SupportedUsageClasses") or []), pb.values(offering_zones.get(name, []))))
+    types_a = np.array(rows, dtype=EC2_TYPE) if rows else np.zeros(0, EC2_TYPE)
+    devs_a = np.array(devs, dtype=EC2_DEVICE) if devs else np.zeros(0, EC2_DEVICE)
+    subnets_a = np.array([(pb.s(s["zone"]), pb.s(s.get("zone_id"))) for s in ctx["subnets"]], dtype=SUBNET) if ctx["subnets"] else np.zeros(0, SUBNET)
+    od_a = np.array([(pb.s(k), float(v)) for k, v in ctx["od_prices"].items()], dtype=OD_PRICE) if ctx["od_prices"] else np.zeros(0, OD_PRICE)
+    sp = ctx.get("spot_prices") or {}
+    spot_a = np.array([(pb.s(k[0]), pb.s(k[1]), float(v)) for k, v in sp.items()], dtype=SPOT_PRICE) if sp else np.zeros(0, SPOT_PRICE)
+    un = ctx.get("unavailable") or ()
+    un_a = np.array([(pb.s(c), pb.s(i), pb.s(z)) for c, i, z in un], dtype=UNAVAILABLE) if un else np.zeros(0, UNAVAILABLE)
+    d = Ec2CatalogDesc()
+    d.types, d.n_types = _ptr(types_a), len(rows)
+    d.devices, d.n_devices = _ptr(devs_a), len(devs)
+    d.subnets, d.n_subnets = _ptr(subnets_a), subnets_a.shape[0]
+    d.od_prices, d.n_od_prices = _ptr(od_a), od_a.shape[0]
+    d.spot_prices, d.n_spot_prices = _ptr(spot_a), spot_a.shape[0]
+    d.unavailable, d.n_unavailable = _ptr(un_a), un_a.shape[0]
+    d.region = pb.s(ctx.get("region", "us-east-1"))
+    d.ami_family = AMI_FAMILIES[ctx.get("ami_family", "AL2023")]
+    d.vm_memory_overhead_percent = float(ctx.get("vm_memory_overhead_percent", 0.075))
+    d.reserved_enis = int(ctx.get("reserved_enis", 0))
+    d.max_pods = -1 if ctx.get("max_pods") is None else int(ctx["max_pods"])
+    d.pods_per_core = -1 if ctx.get("pods_per_core") is None else int(ctx["pods_per_core"])
+    parse_quantity = _parse_quantity
+    d.kube_reserved = Range(*pb.quantity_list({k: parse_quantity(v) for k, v in (ctx.get("kube_reserved") or {}).items()}))
+    d.system_reserved = Range(*pb.quantity_list({k: parse_quantity(v) for k, v in (ctx.get("system_reserved") or {}).items()}))
+    d.eviction_hard = Range(*pb.label_list(ctx.get("eviction_hard") or {}))
+    d.eviction_soft = Range(*pb.label_list(ctx.get("eviction_soft") or {}))
+    d.has_eviction_hard = 1 if ctx.get("eviction_hard") is not None else 0
+    d.has_eviction_soft = 1 if ctx.get("eviction_soft") is not None else 0
+    d.instance_store_policy_raid0 = 1 if ctx.get("instance_store_policy") == "RAID0" else 0
+    bdms = ctx.get("block_device_mappings") or []
+    d.has_block_device_mappings = 1 if bdms else 0
+    root = [b["volume_size"] for b in bdms if b.get("root_volume") and b.get("volume_size") is not None]
+    d.root_volume_milli = int(root[0]) if root else -1
+    d.last_bdm_volume_milli = int(bdms[-1]["volume_size"]) if bdms and bdms[-1].get("volume_size") is not None else -1
+    d.ephemeral_device_volume_milli = int(ctx["ephemeral_device_volume_milli"]) if ctx.get("ephemeral_device_volume_milli") is not None else -1
+    d.pools = pb.finish()
+    return Built(d, [pb, types_a, devs_a, subnets_a, od_a, spot_a, un_a])
+
+
+def _parse_quantity(v):
+    """'100Mi' / '1' / '500m' -> int milli-units (kubelet reserved-resource strings); ints pass through as milli."""
+    if isinstance(v, int):
+        return v
+    import re
+    from fractions import Fraction
+    m = re.fullmatch(r"([0-9.]+)(m|Ki|Mi|Gi|Ti|k|M|G|T|)", str(v).strip())
+    if not m:
+        raise ValueError("bad quantity %r" % (v,))
+    mult = {"m": Fraction(1), "": Fraction(1000), "Ki": 1000 * 1024, "Mi": 1000 * 1024 ** 2, "Gi": 1000 * 1024 ** 3, "Ti": 1000 * 1024 ** 4,
+            "k": 10 ** 6, "M": 10 ** 9, "G": 10 ** 12, "T": 10 ** 15}[m.group(2)]
+    x = Fraction(m.group(1)) * mult
+    return int(-(-x.numerator // x.denominator))

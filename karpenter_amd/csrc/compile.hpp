@@ -52,7 +52,7 @@ struct ParsedPods {
   std::vector<PodRef> pods;
 };
 
-void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out);
+void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out, bool add_pods_one);
 
 struct CNode {
   std::string name;

@@ -96,7 +96,7 @@ std::vector<PTerm> parse_terms(kg_ctx* ctx, const kg_pods_desc* d, kg_range r) {
 }
 }  // namespace
 
-void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out) {
+void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out, bool add_pods_one) {
   if (!d) return;
   const kg_pools& p = d->pools;
   std::unordered_map<std::string, uint32_t> by_sig;
@@ -159,9 +159,11 @@ void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out) {
     PodRef pr;
     pr.cls = cls;
     pr.requests = parse_rl(ctx->V, p, q.requests);
-    bool found = false;
-    for (auto& kv : pr.requests) if (kv.first == ctx->rPods) { kv.second += 1000; found = true; }
-    if (!found) { pr.requests.push_back({ctx->rPods, 1000}); std::sort(pr.requests.begin(), pr.requests.end()); }
+    if (add_pods_one) {  // resources.RequestsForPods adds pods: 1
+      bool found = false;
+      for (auto& kv : pr.requests) if (kv.first == ctx->rPods) { kv.second += 1000; found = true; }
+      if (!found) { pr.requests.push_back({ctx->rPods, 1000}); std::sort(pr.requests.begin(), pr.requests.end()); }
+    }
     pr.uid = std::string(kgdesc::str(p.strings, q.uid));
     pr.creation = q.creation_ts;
     pr.node = q.node;
@@ -284,6 +286,7 @@ struct Compiled {
 };
 
 static SimState sim_at(const Compiled& C, uint8_t* base);
+
 static int find_slot(const Compiled& C, uint32_t key) {
   for (size_t a = 0; a < C.slot_key.size(); ++a) if (C.slot_key[a] == key) return (int)a;
   return -1;
@@ -1169,6 +1172,9 @@ static int32_t fail(kg_ctx* ctx, int32_t code, const std::string& msg) {
   return code;
 }
 
+static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* cluster, const kg_pods_desc* pods,
+                          const kg_nodepools_desc* nodepools, kg_results* out, bool add_pods_one);
+
 #define KG_GUARD_BEGIN try {
 #define KG_GUARD_END(ctx)                                                                   \
   } catch (const kg::Unsupported& e) { return fail(ctx, KG_EUNSUPPORTED, e.what()); }        \
@@ -1323,7 +1329,7 @@ int32_t kg_cluster_upload(kg_ctx* ctx, const kg_cluster_desc* desc, kg_cluster**
     cn.initialized = n.initialized; cn.managed = n.managed; cn.deleting = n.deleting;
     cl->nodes.push_back(std::move(cn));
   }
-  parse_pods(ctx, &desc->pods, &cl->bound);
+  parse_pods(ctx, &desc->pods, &cl->bound, true);
   for (auto& bp : cl->bound.pods) check(bp.node >= 0 && bp.node < (int)cl->nodes.size(), "bound pod node index");
   *out = cl.release();
   return KG_OK;
@@ -1341,9 +1347,19 @@ int32_t kg_solve(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, 
   std::lock_guard<std::mutex> lk(ctx->mu);
   KG_GUARD_BEGIN
   if (n_catalogs != 1) throw Unsupported("one catalog per solve on the device path");
+  return solve_impl(ctx, catalogs, cluster, pods, nodepools, out, true);
+  KG_GUARD_END(ctx)
+}
+
+}  // extern "C"
+
+// Scheduler.Solve on the device + result decode; the caller holds the context lock and the exception guard.
+static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* cluster, const kg_pods_desc* pods,
+                          const kg_nodepools_desc* nodepools, kg_results* out, bool add_pods_one) {
+  {
   auto t0 = std::chrono::steady_clock::now();
   ParsedPods pending;
-  parse_pods(ctx, pods, &pending);
+  parse_pods(ctx, pods, &pending, add_pods_one);
   check(out->cap_pods >= pending.pods.size(), "pod result capacity");
   SolveInputs in{ctx, catalogs[0], cluster, nodepools, &pending};
   const bool stats = ctx->collect_stats;
@@ -1511,8 +1527,10 @@ int32_t kg_solve(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, 
   ctx->stats.device_ms_total += ms_pre + ms_solve;
   ctx->stats.host_compile_ms_total += std::chrono::duration<double, std::milli>(t1 - t0).count();
   return W.overflow ? fail(ctx, KG_ENOMEM, "result buffers too small (see needed_*)") : KG_OK;
-  KG_GUARD_END(ctx)
+  }
 }
+
+extern "C" {
 
 }  // extern "C"
 
@@ -1593,7 +1611,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
 
   // ---- pod universe: pending pods, pods of deleting nodes, then the candidates' reschedulable pods in candidate order
   ParsedPods pend;
-  parse_pods(ctx, pending, &pend);
+  parse_pods(ctx, pending, &pend, true);
   ParsedPods U;
   U.classes = pend.classes;
   const uint32_t cls_off = (uint32_t)U.classes.size();
@@ -1899,6 +1917,158 @@ int32_t kg_consolidate_select(kg_ctx* ctx, kg_catalog* catalog, int32_t multi, c
     for (uint32_t t : types) { if (out->n_types < out->cap_type_ids && out->type_ids) out->type_ids[out->n_types] = t; out->n_types++; }
   }
   return KG_OK;
+  KG_GUARD_END(ctx)
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ launch side (CloudProvider.Create)
+namespace {
+
+// zone / capacity-type admissible sets of a NodeClaim's requirements + its minValues, for price ordering
+void launch_view(kg_ctx* ctx, kg_catalog* cat, const HReqs& reqs, ClaimView* cv) {
+  Vocab& V = ctx->V;
+  auto mask_of = [&](uint32_t key) -> uint64_t {
+    const HReq* r = reqs.find(key);
+    if (!r) return ~0ull;
+    uint64_t m = 0;
+    for (uint32_t v = 0; v < V.vals[key].size() && v < 64; ++v) if (r->has(V, v)) m |= 1ull << v;
+    return m;
+  };
+  cv->zmask = mask_of(ctx->kZone);
+  cv->ctmask = mask_of(ctx->kCT);
+  if (reqs.find(ctx->kZid)) {
+    const uint64_t zidm = mask_of(ctx->kZid);
+    const uint8_t* zone_zid = cat->tab.image.bytes.data() + cat->tab.o_zone_zid;
+    for (int z = 0; z < 64; ++z) if (zone_zid[z] != 0xFF && !((zidm >> zone_zid[z]) & 1)) cv->zmask &= ~(1ull << z);
+  }
+  for (auto& q : reqs.rs) if (q.min_values >= 0) cv->minvals.push_back({q.key, q.min_values});
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t kg_truncate(kg_ctx* ctx, kg_catalog* catalog, const kg_pools* pools, kg_range requirements, const uint32_t* type_ids, uint32_t n_types,
+                    int32_t max_types, uint32_t* out_type_ids, uint32_t* n_out, uint8_t* min_values_failed) {
+  if (!ctx || !catalog || !pools || (!type_ids && n_types) || !out_type_ids || !n_out) return KG_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  KG_GUARD_BEGIN
+  HReqs reqs = parse_reqs(ctx->V, *pools, requirements);
+  ClaimView cv;
+  launch_view(ctx, catalog, reqs, &cv);
+  for (uint32_t i = 0; i < n_types; ++i) { check(type_ids[i] < catalog->types.size(), "type id"); cv.types.push_back(type_ids[i]); }
+  const bool ok = truncate_types(catalog, cv, max_types);
+  if (min_values_failed) *min_values_failed = !ok;
+  *n_out = (uint32_t)cv.types.size();  // (on a minValues failure: the ordered, untruncated list; never more than n_types)
+  for (size_t i = 0; i < cv.types.size(); ++i) out_type_ids[i] = cv.types[i];
+  return KG_OK;
+  KG_GUARD_END(ctx)
+}
+
+int32_t kg_launch_filter(kg_ctx* ctx, kg_catalog* catalog, const kg_pools* pools, kg_range requirements, kg_range requests, int32_t max_types,
+                         uint32_t* out_type_ids, uint32_t cap, uint32_t* n_out, uint8_t* min_values_failed) {
+  if (!ctx || !catalog || !pools || !n_out || (!out_type_ids && cap)) return KG_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  KG_GUARD_BEGIN
+  check(pools->strings.count > 0, "launch filter needs a non-empty string table");
+  Vocab& V = ctx->V;
+  // resolveInstanceTypes (cloudprovider.go:267-282) == NodeClaim.Add of one pod that carries the claim's requests on a
+  // fresh claim whose template carries the claim's requirements: run exactly that on the device.
+  kg_nodepool np{};
+  np.name = 0;
+  np.requirements = requirements;
+  kg_nodepools_desc nps{};
+  nps.pools = *pools;
+  // (minValues play no part in resolveInstanceTypes; Truncate checks them afterwards)
+  std::vector<kg_requirement> plain(pools->reqs, pools->reqs + pools->n_reqs);
+  for (auto& q : plain) q.min_values = -1;
+  nps.pools.reqs = plain.data();
+  nps.nodepools = &np;
+  nps.n_nodepools = 1;
+  nps.max_instance_types = 0;
+  kg_pod pod{};
+  pod.uid = 0; pod.ns = 0;
+  pod.requests = requests;
+  pod.node = -1;
+  kg_pods_desc pd{};
+  pd.pools = *pools;
+  pd.pods = &pod;
+  pd.n_pods = 1;
+  const uint32_t T = (uint32_t)catalog->types.size();
+  std::vector<uint32_t> type_ids(std::max(T, 1u)), value_ids(4096), str_offsets(1024);
+  std::vector<kg_claim_out> claims(1);
+  std::vector<kg_req_out> rq(64);
+  std::vector<kg_quantity> qs(64);
+  std::vector<char> str_data(65536);
+  uint8_t pod_kind = 0; int32_t pod_index = -1; uint32_t pod_reason = 0;
+  kg_results res{};
+  res.pod_kind = &pod_kind; res.pod_index = &pod_index; res.pod_reason = &pod_reason; res.cap_pods = 1;
+  res.claims = claims.data(); res.cap_claims = 1;
+  res.type_ids = type_ids.data(); res.cap_type_ids = (uint32_t)type_ids.size();
+  res.reqs = rq.data(); res.cap_reqs = (uint32_t)rq.size();
+  res.value_ids = value_ids.data(); res.cap_value_ids = (uint32_t)value_ids.size();
+  res.quantities = qs.data(); res.cap_quantities = (uint32_t)qs.size();
+  res.str_data = str_data.data(); res.cap_str_data = (uint32_t)str_data.size();
+  res.str_offsets = str_offsets.data(); res.cap_strs = (uint32_t)str_offsets.size();
+  kg_catalog* cats[1] = {catalog};
+  const bool stats = ctx->collect_stats;
+  ctx->collect_stats = false;
+  const int32_t st = solve_impl(ctx, cats, nullptr, &pd, &nps, &res, false);
+  ctx->collect_stats = stats;
+  if (st != KG_OK && st != KG_ENOMEM) return st;
+  ClaimView cv;
+  HReqs reqs = parse_reqs(V, *pools, requirements);
+  launch_view(ctx, catalog, reqs, &cv);
+  if (pod_kind == KG_POD_NEW_CLAIM && res.n_claims == 1)
+    for (uint32_t i = 0; i < claims[0].types.count; ++i) cv.types.push_back(type_ids[claims[0].types.begin + i]);
+  if (cv.minvals.empty() && !cv.types.empty()) {
+    // filterInstanceTypes (instance.go:389-399): only without minValues
+    const int kSize = V.keys.find("karpenter.k8s.aws/instance-size");
+    const char* exotic[] = {"aws.amazon.com/neuron", "amd.com/gpu", "nvidia.com/gpu", "habana.ai/gaudi"};
+    std::vector<uint32_t> generic;
+    for (uint32_t t : cv.types) {
+      const CatType& ty = catalog->types[t];
+      bool skip = false;
+      if (kSize >= 0)
+        if (const HReq* r = ty.reqs.find((uint32_t)kSize))
+          for (uint32_t v : r->vals) skip |= V.vals[kSize].strs[v].find("metal") != std::string::npos;
+      for (const char* rn : exotic) {
+        const int rid = V.resources.find(rn);
+        if (rid >= 0) for (auto& kv : ty.capacity) if ((int)kv.first == rid && kv.second != 0) skip = true;
+      }
+      if (!skip) generic.push_back(t);
+    }
+    if (!generic.empty()) cv.types.swap(generic);
+    // isMixedCapacityLaunch + filterUnwantedSpot
+    const int spot = V.vals[ctx->kCT].find("spot"), od = V.vals[ctx->kCT].find("on-demand");
+    if (spot >= 0 && od >= 0 && ((cv.ctmask >> spot) & 1) && ((cv.ctmask >> od) & 1)) {
+      bool has_spot = false, has_od = false;
+      for (uint32_t t : cv.types)
+        for (auto& o : catalog->types[t].offerings) {
+          if (!o.available || !((cv.zmask >> o.zone) & 1) || !((cv.ctmask >> o.ct) & 1)) continue;
+          if ((int)o.ct == spot) has_spot = true; else has_od = true;
+        }
+      if (has_spot && has_od) {
+        double cheapest_od = std::numeric_limits<double>::max();
+        for (uint32_t t : cv.types)
+          for (auto& o : catalog->types[t].offerings) if (o.available && (int)o.ct == od && o.price < cheapest_od) cheapest_od = o.price;
+        std::vector<uint32_t> kept;
+        for (uint32_t t : cv.types) {
+          bool any = false;
+          double best = 0;
+          for (auto& o : catalog->types[t].offerings) if (o.available && (!any || o.price < best)) { best = o.price; any = true; }
+          if (any && best <= cheapest_od) kept.push_back(t);
+        }
+        cv.types.swap(kept);
+      }
+    }
+  }
+  const bool ok = truncate_types(catalog, cv, max_types);
+  if (min_values_failed) *min_values_failed = !ok;
+  *n_out = (uint32_t)cv.types.size();
+  for (size_t i = 0; i < cv.types.size() && i < cap; ++i) out_type_ids[i] = cv.types[i];
+  return cv.types.size() > cap ? fail(ctx, KG_ENOMEM, "type id buffer too small") : KG_OK;
   KG_GUARD_END(ctx)
 }
 

@@ -35,6 +35,9 @@ class Library:
         d.kg_destroy.argtypes = [C.c_void_p]
         d.kg_catalog_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
         d.kg_catalog_free.argtypes = [C.c_void_p]
+        d.kg_catalog_build_ec2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+        d.kg_catalog_query.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+        d.kg_catalog_size.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
         d.kg_cluster_upload.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         d.kg_cluster_free.argtypes = [C.c_void_p]
         d.kg_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -42,6 +45,10 @@ class Library:
         for fn in (d.kg_consolidate_single, d.kg_consolidate_multi):
             fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                            C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+        d.kg_launch_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, abi.Range, abi.Range, C.c_int32, C.c_void_p, C.c_uint32,
+                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
+        d.kg_truncate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, abi.Range, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p,
+                                  C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
         d.kg_consolidate_select.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         d.kg_set_collect_stats.argtypes = [C.c_void_p, C.c_int32]
         self.ctx = C.c_void_p()
@@ -66,6 +73,28 @@ class Library:
         h = C.c_void_p()
         self._check(self.dll.kg_catalog_upload(self.ctx, C.addressof(built.desc), generation, C.byref(h)))
         return h
+
+    def catalog_build_ec2(self, built, generation=1):
+        """The List() miss path natively: raw EC2 facts -> instance types (offerings, requirements, capacity, overhead)."""
+        h = C.c_void_p()
+        self._check(self.dll.kg_catalog_build_ec2(self.ctx, C.addressof(built.desc), generation, C.byref(h)))
+        return h
+
+    def catalog_query(self, catalog, type_index, resources):
+        """-> (name, {resource: capacity milli}, {resource: allocatable milli})"""
+        arr = (C.c_char_p * len(resources))(*[r.encode() for r in resources])
+        cap = (C.c_int64 * len(resources))()
+        alloc = (C.c_int64 * len(resources))()
+        name = C.create_string_buffer(128)
+        st = self.dll.kg_catalog_query(catalog, type_index, arr, len(resources), cap, alloc, name, 128)
+        if st != 0:
+            raise KgError(st, "kg_catalog_query")
+        return name.value.decode(), dict(zip(resources, cap)), dict(zip(resources, alloc))
+
+    def catalog_size(self, catalog):
+        n, g = C.c_uint32(0), C.c_uint64(0)
+        self.dll.kg_catalog_size(catalog, C.byref(n), C.byref(g))
+        return n.value, g.value
 
     def cluster_upload(self, built):
         h = C.c_void_p()
@@ -95,6 +124,26 @@ class Library:
         self._check(self.dll.kg_consolidate_select(self.ctx, catalog, 1 if multi else 0, records.ctypes.data if len(records) else None,
                                                    len(records), n_candidates, C.addressof(db.dec)))
         return db.decode()
+
+    def launch_filter(self, catalog, requirements, requests, max_types=60):
+        """resolveInstanceTypes -> filterInstanceTypes -> Truncate for one NodeClaim -> (type ids, minValues failed)."""
+        import numpy as np
+        pools, rr, qq = abi.build_launch(requirements, requests)
+        out = np.zeros(4096, "<u4")
+        n, mv = C.c_uint32(0), C.c_uint8(0)
+        self._check(self.dll.kg_launch_filter(self.ctx, catalog, C.addressof(pools.desc), rr, qq, max_types, out.ctypes.data, out.shape[0],
+                                              C.byref(n), C.byref(mv)))
+        return out[:n.value].tolist(), bool(mv.value)
+
+    def truncate(self, catalog, requirements, type_ids, max_types=60):
+        import numpy as np
+        pools, rr, _ = abi.build_launch(requirements, {})
+        ids = np.array(list(type_ids), dtype="<u4")
+        out = np.zeros(max(len(ids), 1), "<u4")
+        n, mv = C.c_uint32(0), C.c_uint8(0)
+        self._check(self.dll.kg_truncate(self.ctx, catalog, C.addressof(pools.desc), rr, ids.ctypes.data if len(ids) else None, len(ids), max_types,
+                                         out.ctypes.data, C.byref(n), C.byref(mv)))
+        return out[:n.value].tolist(), bool(mv.value)
 
     def close(self):
         if self.ctx:

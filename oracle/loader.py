@@ -28,6 +28,12 @@ def lib():
         _LIB.ko_consolidate_records.restype = C.c_int32
         _LIB.ko_consolidate_records.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                                 C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+        _LIB.ko_launch_filter.restype = C.c_int32
+        _LIB.ko_launch_filter.argtypes = [C.c_void_p, C.c_void_p, abi.Range, abi.Range, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                          C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
+        _LIB.ko_truncate.restype = C.c_int32
+        _LIB.ko_truncate.argtypes = [C.c_void_p, C.c_void_p, abi.Range, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, C.POINTER(C.c_uint32),
+                                     C.POINTER(C.c_uint8)]
         _LIB.ko_consolidate_decide.restype = C.c_int32
         _LIB.ko_consolidate_decide.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     return _LIB
@@ -69,3 +75,27 @@ def consolidate_decide(catalogs, cluster, pending, nodepools, cands, multi, cap_
     st = lib().ko_consolidate_decide(arr, len(catalogs), C.addressof(cluster.desc), C.addressof(pending.desc), C.addressof(nodepools.desc),
                                      C.addressof(cands.desc), 1 if multi else 0, C.addressof(db.dec))
     return st, db.decode()
+
+
+def launch_filter(catalog, requirements, requests, well_known, max_types=60):
+    import numpy as np
+    pools, rr, qq = abi.build_launch(requirements, requests)
+    wk = (C.c_char_p * len(well_known))(*[w.encode() for w in well_known])
+    out = np.zeros(4096, "<u4")
+    n, mv = C.c_uint32(0), C.c_uint8(0)
+    st = lib().ko_launch_filter(C.addressof(catalog.desc), C.addressof(pools.desc), rr, qq, max_types, wk, len(well_known), out.ctypes.data,
+                                out.shape[0], C.byref(n), C.byref(mv))
+    assert st == 0
+    return out[:n.value].tolist(), bool(mv.value)
+
+
+def truncate(catalog, requirements, type_ids, max_types=60):
+    import numpy as np
+    pools, rr, _ = abi.build_launch(requirements, {})
+    ids = np.array(list(type_ids), dtype="<u4")
+    out = np.zeros(max(len(ids), 1), "<u4")
+    n, mv = C.c_uint32(0), C.c_uint8(0)
+    st = lib().ko_truncate(C.addressof(catalog.desc), C.addressof(pools.desc), rr, ids.ctypes.data if len(ids) else None, len(ids), max_types,
+                           out.ctypes.data, C.byref(n), C.byref(mv))
+    assert st == 0
+    return out[:n.value].tolist(), bool(mv.value)

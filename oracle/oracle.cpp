@@ -1588,4 +1588,101 @@ int32_t ko_consolidate_decide(const kg_catalog_desc* const* catalogs, uint32_t n
   }
 }
 
+
+// InstanceTypes.Truncate(reqs, max) over the given catalog types (pkg/providers/instance/instance.go:101)
+int32_t ko_truncate(const kg_catalog_desc* catalog, const kg_pools* pools, kg_range requirements, const uint32_t* type_ids, uint32_t n_types,
+                    int32_t max_types, uint32_t* out_type_ids, uint32_t* n_out, uint8_t* min_values_failed) {
+  try {
+    Problem pr;
+    G = &pr.in;
+    SchedCtx& C = pr.C;
+    C.keyZone = pr.in.id("topology.kubernetes.io/zone"); C.keyCT = pr.in.id("karpenter.sh/capacity-type"); C.keyZoneID = pr.in.id("topology.k8s.aws/zone-id");
+    Parser P{pr.in};
+    auto cat = parseCatalog(pr.in, catalog, C.keyCT, C.keyZone, C.keyZoneID);
+    Requirements reqs = P.reqs(*pools, requirements);
+    vector<InstanceType*> its;
+    for (uint32_t i = 0; i < n_types; ++i) { check(type_ids[i] < cat->types.size(), "type id"); its.push_back(cat->types[type_ids[i]].get()); }
+    for (const char* k : {"karpenter.sh/nodepool", "topology.kubernetes.io/zone", "karpenter.sh/capacity-type", "topology.k8s.aws/zone-id"}) C.wellKnown.insert(pr.in.id(k));
+    vector<InstanceType*> out;
+    const bool ok = Truncate(its, reqs, max_types, C, &out);
+    if (min_values_failed) *min_values_failed = !ok;
+    *n_out = (uint32_t)out.size();
+    for (size_t i = 0; i < out.size(); ++i) out_type_ids[i] = (uint32_t)out[i]->index;
+    return KG_OK;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "ko_truncate: %s\n", e.what());
+    return KG_EINVAL;
+  }
+}
+
+// CloudProvider.Create's launch-side selection: resolveInstanceTypes (pkg/cloudprovider/cloudprovider.go:267-282), then
+// without minValues filterExoticInstanceTypes + (isMixedCapacityLaunch ? filterUnwantedSpot) (instance.go:389-477), then
+// Truncate(reqs, max) (instance.go:101).
+int32_t ko_launch_filter(const kg_catalog_desc* catalog, const kg_pools* pools, kg_range requirements, kg_range requests, int32_t max_types,
+                         const char* const* well_known, uint32_t n_well_known, uint32_t* out_type_ids, uint32_t cap, uint32_t* n_out,
+                         uint8_t* min_values_failed) {
+  try {
+    Problem pr;
+    G = &pr.in;
+    SchedCtx& C = pr.C;
+    C.keyZone = pr.in.id("topology.kubernetes.io/zone"); C.keyCT = pr.in.id("karpenter.sh/capacity-type"); C.keyZoneID = pr.in.id("topology.k8s.aws/zone-id");
+    C.valSpot = pr.in.id("spot"); C.valOnDemand = pr.in.id("on-demand");
+    for (uint32_t i = 0; i < n_well_known; ++i) C.wellKnown.insert(pr.in.id(well_known[i]));
+    Parser P{pr.in};
+    auto cat = parseCatalog(pr.in, catalog, C.keyCT, C.keyZone, C.keyZoneID);
+    Requirements reqs = P.reqs(*pools, requirements);
+    RL req = P.rl(*pools, requests);
+    vector<InstanceType*> its;
+    for (auto& t : cat->types) {
+      InstanceType* it = t.get();
+      if (!reqs.Compatible(it->reqs, &C.wellKnown)) continue;
+      bool off = false;
+      for (auto& o : it->offerings) if (o.available && offeringCompatible(reqs, o, C)) { off = true; break; }
+      if (!off || !Fits(req, it->allocatable)) continue;
+      its.push_back(it);
+    }
+    if (!reqs.HasMinValues()) {
+      const int keySize = pr.in.id("karpenter.k8s.aws/instance-size");
+      vector<InstanceType*> generic;
+      for (auto* it : its) {
+        bool skip = false;
+        for (int v : it->reqs.Get(keySize).values) skip |= G->s(v).find("metal") != string::npos;
+        for (const char* rn : {"aws.amazon.com/neuron", "amd.com/gpu", "nvidia.com/gpu", "habana.ai/gaudi"}) skip |= rlGet(it->capacity, pr.in.id(rn)) != 0;
+        if (!skip) generic.push_back(it);
+      }
+      if (!generic.empty()) its = generic;
+      const Requirement ct = reqs.Get(C.keyCT);
+      if (ct.Has(C.valSpot) && ct.Has(C.valOnDemand)) {
+        bool hasSpot = false, hasOD = false;
+        for (auto* it : its)
+          for (auto& o : it->offerings) {
+            if (!o.available || !offeringCompatible(reqs, o, C)) continue;
+            if (o.ct == C.valSpot) hasSpot = true; else hasOD = true;
+          }
+        if (hasSpot && hasOD) {
+          double cheapestOD = std::numeric_limits<double>::max();
+          for (auto* it : its) for (auto& o : it->offerings) if (o.available && o.ct == C.valOnDemand && o.price < cheapestOD) cheapestOD = o.price;
+          vector<InstanceType*> kept;
+          for (auto* it : its) {
+            bool any = false;
+            double best = 0;
+            for (auto& o : it->offerings) if (o.available && (!any || o.price < best)) { best = o.price; any = true; }
+            if (any && best <= cheapestOD) kept.push_back(it);
+          }
+          its = kept;
+        }
+      }
+    }
+    vector<InstanceType*> out;
+    const bool ok = Truncate(its, reqs, max_types, C, &out);
+    if (min_values_failed) *min_values_failed = !ok;
+    *n_out = (uint32_t)out.size();
+    for (size_t i = 0; i < out.size() && i < cap; ++i) out_type_ids[i] = (uint32_t)out[i]->index;
+    return KG_OK;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "ko_launch_filter: %s\n", e.what());
+    return KG_EINVAL;
+  }
+}
+
 }  // extern "C"

@@ -1,0 +1,59 @@
+"""kg_catalog_build_ec2 (the List() miss path done by the library) against the catalog oracle, which is itself pinned on
+the reference's 776 documented rows (tests/test_catalog_oracle.py): same capacity / allocatable per resource for every
+type, and the same behaviour as an uploaded catalog in Solve and in the launch filter."""
+from karpenter_amd import abi, workloads as wl
+from oracle import catalog_oracle as co, loader
+from tests.helpers import Problem, diff_results, families
+
+RES = [co.RES_CPU, co.RES_MEM, co.RES_EPH, co.RES_PODS, co.RES_POD_ENI, co.RES_NVIDIA, co.RES_AMD, co.RES_NEURON, co.RES_GAUDI, co.RES_EFA,
+       co.RES_PRIVATE_IPV4]
+
+
+def _check_tables(L, infos, ctx, oz):
+    types = co.list_instance_types(infos, ctx, ctx["limits"], ctx["bandwidth"], oz)
+    h = L.catalog_build_ec2(abi.build_ec2_catalog(infos, ctx, ctx["limits"], ctx["bandwidth"], oz))
+    try:
+        assert L.catalog_size(h)[0] == len(types)
+        for i, t in enumerate(types):
+            name, cap, alloc = L.catalog_query(h, i, RES)
+            assert name == t["name"]
+            exp_alloc = co.allocatable(t)
+            for r in RES:
+                assert cap[r] == t["capacity"].get(r, 0), (name, r, cap[r], t["capacity"].get(r, 0))
+                assert alloc[r] == exp_alloc.get(r, 0), (name, r, alloc[r], exp_alloc.get(r, 0))
+    finally:
+        L.dll.kg_catalog_free(h)
+    return types
+
+
+def check_ec2_build(L):
+    zones = wl.zones_n(3)
+    infos = wl.ec2_facts_776()
+    base = wl.ec2_context(zones)
+    oz = {i["InstanceType"]: zones for i in infos}
+    oz[infos[5]["InstanceType"]] = zones[:1]          # a type offered in one zone only
+    variants = [
+        dict(base),
+        dict(base, ami_family="Bottlerocket", pods_per_core=2, reserved_enis=1),
+        dict(base, ami_family="AL2", max_pods=58, kube_reserved={"cpu": "250m", "memory": "1Gi"}, system_reserved={"memory": "200Mi"},
+             eviction_hard={"memory.available": "5%", "nodefs.available": "15%"}, eviction_soft={"memory.available": "750Mi"}),
+        dict(base, ami_family="Windows2022", pods_per_core=4),
+        dict(base, ami_family="AL2023", instance_store_policy="RAID0", unavailable={("spot", infos[0]["InstanceType"], zones[0]), ("on-demand", infos[9]["InstanceType"], zones[2])}),
+    ]
+    for ctx in variants:
+        types = _check_tables(L, infos, ctx, oz)
+    # behaviour: a Solve over the natively built catalog == a Solve over the uploaded oracle catalog
+    ctx = variants[-1]
+    types = co.list_instance_types(infos, ctx, ctx["limits"], ctx["bandwidth"], oz)
+    prob = Problem(types, wl.mixed_pods(300, 1, zones, families(types)), [wl.default_nodepool()])
+    h = L.catalog_build_ec2(abi.build_ec2_catalog(infos, ctx, ctx["limits"], ctx["bandwidth"], oz))
+    try:
+        ro, rg = prob.run_oracle(), prob.run_library(L, h)
+        d = diff_results(ro.decode(), rg.decode())
+        assert d == "", d
+        cat = abi.build_catalog(types)
+        for reqs, requests in (([(wl.L_CT, "In", ["on-demand", "spot"])], {"cpu": 1000, "pods": 1000}),
+                               ([(wl.L_CT, "In", ["spot"]), (wl.L_ZONE, "In", [zones[0]])], {"cpu": 500, "pods": 1000})):
+            assert L.launch_filter(h, reqs, requests) == loader.launch_filter(cat, reqs, requests, wl.WELL_KNOWN_LABELS)
+    finally:
+        L.dll.kg_catalog_free(h)

@@ -69,3 +69,14 @@ def test_c2_full(L):
 def test_scenarios(L, name):
     """C3 topology spread / anti-affinity, existing nodes, C5 weighted NodePools with limits -- bit for bit vs the oracle."""
     check(L, scenario(name))
+
+
+def test_launch_filter_and_truncate(L):
+    from tests.launch_common import check_launch, check_reference_pins
+    check_launch(L)
+    check_reference_pins(L)
+
+
+def test_catalog_build_ec2(L):
+    from tests.catalog_common import check_ec2_build
+    check_ec2_build(L)

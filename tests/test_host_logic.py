@@ -73,3 +73,14 @@ def test_scenarios(L, name):
     ro, _ = check(L, scenario(name))
     if name.startswith("existing") or name.startswith("c5"):
         assert any(k == 1 for k, _ in ro.decode()["pods"])
+
+
+def test_launch_filter_and_truncate(L):
+    from tests.launch_common import check_launch, check_reference_pins
+    check_launch(L)
+    check_reference_pins(L)
+
+
+def test_catalog_build_ec2(L):
+    from tests.catalog_common import check_ec2_build
+    check_ec2_build(L)
