@@ -1382,8 +1382,8 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
   hal::d2h(header.data(), sp(C->o_header), 64);
   hal::d2h(counters.data(), sp(C->o_counters), 256);
   if (ctx->collect_timers) {
-    static const char* names[] = {"pop+ctx", "nodes", "prefilter", "sort", "eval", "stats", "commit", "newclaim/relax"};
-    for (int i = 0; i < 8; ++i) fprintf(stderr, "[kg timers] %-15s %10.3f ms\n", names[i], counters[8 + i] / 1e5);
+    static const char* names[] = {"pop+ctx", "nodes", "prefilter", "sort", "eval.rest", "stats", "commit", "newclaim/relax", "eval.load", "eval.merge", "eval.word", "eval.pick"};
+    for (int i = 0; i < 12; ++i) fprintf(stderr, "[kg timers] %-15s %10.3f ms\n", names[i], counters[8 + i] / 1e5);
     fprintf(stderr, "[kg timers] shader clock %.0f MHz over the launch\n", counters[25] ? counters[24] / (counters[25] / 100.0) : 0.0);
     fprintf(stderr, "[kg timers] probes (ns each): barrier %.0f, dependent global load %.0f, LDS store+2 barriers+LDS load %.0f, global store+barrier %.0f\n",
             counters[26] * 10.0 / 1000, counters[27] * 10.0 / 1000, counters[28] * 10.0 / 1000, counters[29] * 10.0 / 1000);

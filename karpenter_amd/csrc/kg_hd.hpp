@@ -16,6 +16,8 @@
 #define KG_DEVICE_ONLY 0
 #define KG_FOR_THREADS(tid, nthreads) for (int tid = 0; tid < (nthreads); ++tid)
 #define KG_SYNC() ((void)0)
+#define KG_GLOBAL
+#define KG_OPAQUE64(x) ((void)0)
 struct alignas(16) uint4 { uint32_t x, y, z, w; };
 namespace kg {
 inline void atomic_min_u32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
@@ -34,6 +36,16 @@ inline int ctz64(uint64_t x) { return __builtin_ctzll(x); }
 #define KG_DEVICE_ONLY 1
 #define KG_FOR_THREADS(tid, nthreads) for (int tid = (int)threadIdx.x, kg_once_ = 0; kg_once_ == 0; kg_once_ = 1)
 #define KG_SYNC() __syncthreads()
+// Pointers into device memory that the kernels load from memory (not from the kernel arguments) are typed as global
+// address space in the device pass: otherwise the compiler emits flat loads, whose completion also counts on the LDS
+// counter, and every LDS read in the same phase then waits for all outstanding memory loads.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KG_GLOBAL __attribute__((address_space(1)))
+#else
+#define KG_GLOBAL
+#endif
+// keeps the compiler from merging an LDS load and a global load of two branches into one flat load behind a pointer select
+#define KG_OPAQUE64(x) asm volatile("" : "+v"(x))
 namespace kg {
 // workgroup-shared (LDS) minimum
 __device__ __forceinline__ void atomic_min_u32(uint32_t* p, uint32_t v) { atomicMin(p, v); }

@@ -26,6 +26,9 @@
 #pragma once
 #include "kg_hd.hpp"
 
+#ifndef KG_EXP
+#define KG_EXP 0
+#endif
 namespace kg {
 
 constexpr int KG_MAXR = 8;      // active resources in one solve (requested by a pod, daemon overhead, or limited)
@@ -182,32 +185,32 @@ struct DevProblem {
 
 // Mutable state of ONE simulation (device pointers into that simulation's arena).
 struct SimState {
-  int64_t* nreq;      // [R][N]
-  int64_t* c_req;     // [R][Cmax]
-  int64_t* c_head;    // [R][Cmax] upper bound of what the claim can still take: max allocatable over its options - c_req
-  uint64_t* c_mask;   // [TW][Cmax]
-  uint64_t* c_bits;   // [Wa][Cmax]
-  uint32_t* c_meta;   // [Ka][Cmax]
-  uint32_t* c_npods;  // [Cmax]
-  uint16_t* c_tmpl;   // [Cmax]
-  uint32_t* c_hstamp; // [Cmax] c_stamp at the last exact recomputation of c_head
-  uint32_t* c_stamp;  // [Cmax] step of the claim's creation / last pod: with c_npods it is the claim's place in the
+  KG_GLOBAL int64_t* nreq;      // [R][N]
+  KG_GLOBAL int64_t* c_req;     // [R][Cmax]
+  KG_GLOBAL int64_t* c_head;    // [R][Cmax] upper bound of what the claim can still take: max allocatable over its options - c_req
+  KG_GLOBAL uint64_t* c_mask;   // [TW][Cmax]
+  KG_GLOBAL uint64_t* c_bits;   // [Wa][Cmax]
+  KG_GLOBAL uint32_t* c_meta;   // [Ka][Cmax]
+  KG_GLOBAL uint32_t* c_npods;  // [Cmax]
+  KG_GLOBAL uint16_t* c_tmpl;   // [Cmax]
+  KG_GLOBAL uint32_t* c_hstamp; // [Cmax] c_stamp at the last exact recomputation of c_head
+  KG_GLOBAL uint32_t* c_stamp;  // [Cmax] step of the claim's creation / last pod: with c_npods it is the claim's place in the
                       // reference's (stable) sort.Slice order -- see claim_key()
-  int64_t* remaining; // [R][NP]
-  int32_t* gcount;    // [G][64]
-  uint64_t* gdom;     // [G] registered domains
-  uint64_t* gpos;     // [G] domains with count > 0
-  int32_t* hcount;    // [GH][H]
-  int32_t* hpos;      // [GH] hosts with count > 0
-  uint32_t* queue;    // [P+1][4] ring of {pod, variant, lastLen epoch, lastLen value}: one 16-byte load per Queue.Pop
-  uint8_t* pod_kind;  // [P]
-  int32_t* pod_index; // [P]
-  uint32_t* pod_reason; // [P]
-  uint64_t* scratch;  // [TW+1][Cmax] candidate option masks of the survivors; row TW: per-claim visit statistic
-  uint32_t* header;   // [16]: 0 nclaims, 1 relaxations, 2-5 the claim touched after the last sort (id, old pods, old stamp, new)
-  const uint64_t* excl; // [NW] existing nodes left out of this simulation (consolidation candidates)
+  KG_GLOBAL int64_t* remaining; // [R][NP]
+  KG_GLOBAL int32_t* gcount;    // [G][64]
+  KG_GLOBAL uint64_t* gdom;     // [G] registered domains
+  KG_GLOBAL uint64_t* gpos;     // [G] domains with count > 0
+  KG_GLOBAL int32_t* hcount;    // [GH][H]
+  KG_GLOBAL int32_t* hpos;      // [GH] hosts with count > 0
+  KG_GLOBAL uint32_t* queue;    // [P+1][4] ring of {pod, variant, lastLen epoch, lastLen value}: one 16-byte load per Queue.Pop
+  KG_GLOBAL uint8_t* pod_kind;  // [P]
+  KG_GLOBAL int32_t* pod_index; // [P]
+  KG_GLOBAL uint32_t* pod_reason; // [P]
+  KG_GLOBAL uint64_t* scratch;  // [TW+1][Cmax] candidate option masks of the survivors; row TW: per-claim visit statistic
+  KG_GLOBAL uint32_t* header;   // [16]: 0 nclaims, 1 relaxations, 2-5 the claim touched after the last sort (id, old pods, old stamp, new)
+  const KG_GLOBAL uint64_t* excl; // [NW] existing nodes left out of this simulation (consolidation candidates)
   uint32_t n_shared, pod_base, qcap;  // pods [0,n_shared) and [pod_base, ...) take part; result rows are local indices
-  uint64_t* counters; // [32]: 8.. phase timers and scan statistics when stats&2; [0..3]: visited_existing, visited_claims, visited_claim_types, new_claim_scans
+  KG_GLOBAL uint64_t* counters; // [32]: 8.. phase timers and scan statistics when stats&2; [0..3]: visited_existing, visited_claims, visited_claim_types, new_claim_scans
 };
 
 // One evaluation group's working copy of a NodeClaim (LDS): the claim's requirement row is loaded here, the pod is
@@ -404,10 +407,6 @@ KG_HD unsigned long long claim_key(uint32_t npods, uint32_t stamp, uint32_t c) {
 }
 
 // ------------------------------------------------------------------ NodeClaim.Add on a claim row held in LDS
-KG_HD const uint64_t* entry_bits(const DevProblem& P, const Shared& sh, const PodEntry& pe) {
-  return pe.bits != 0xFFFF ? sh.vc.ebits + pe.bits : P.rs_bits + P.e_bits[pe.e];
-}
-
 KG_HD SReq row_special(const Shared& sh, const Row& R, int i) {
   const int a = sh.spec_slot[i];
   SReq r;
@@ -417,7 +416,8 @@ KG_HD SReq row_special(const Shared& sh, const Row& R, int i) {
 }
 
 // Requirement.Intersection of row slot a (w words at off) with (pm, pb), in place.  Returns the merged meta.
-KG_HD uint32_t row_intersect(const DevProblem& P, Row& R, int a, int w, int off, uint32_t pm, const uint64_t* pb, bool* any, bool* changed,
+template <typename BitsPtr>
+KG_HD uint32_t row_intersect(const DevProblem& P, Row& R, int a, int w, int off, uint32_t pm, BitsPtr pb, bool* any, bool* changed,
                              bool* cany) {
   const uint32_t cm = R.meta[a];
   const bool xc = cm & RM_COMPL, yc = pm & RM_COMPL;
@@ -446,10 +446,9 @@ KG_HD uint32_t row_intersect(const DevProblem& P, Row& R, int a, int w, int off,
 
 // Step 3 of NodeClaim.Add for ONE pod requirement entry j: Requirements.Compatible(podReqs) + Add on that key.
 // Entries of one requirement set are on distinct keys, so the entries of a pod merge in parallel.
-KG_HD void row_merge_entry(const DevProblem& P, const Shared& sh, Row& R, uint32_t j, bool fresh) {
-  const PodEntry pe = sh.vc.ent[j];
+template <typename BitsPtr>  // the entry's value words: LDS (VariantCtx::ebits) or the global requirement-set table
+KG_HD void row_merge_entry_from(const DevProblem& P, const Shared& sh, Row& R, uint32_t j, bool fresh, const PodEntry pe, BitsPtr pb) {
   const int a = pe.slot;
-  const uint64_t* pb = entry_bits(P, sh, pe);
   const uint32_t cm = R.meta[a];
   if (!(cm & RM_PRESENT)) {
     if (!((P.well_known_slots >> a) & 1) && !op_neg(pe.opc)) { R.ok = 0; atomic_or_u32(&R.reason, 2u); return; }
@@ -470,6 +469,13 @@ KG_HD void row_merge_entry(const DevProblem& P, const Shared& sh, Row& R, uint32
   if (pe.spec >= 0 && chg) atomic_or_u32(&R.sp_changed, 1u << pe.spec);
 }
 
+KG_HD void row_merge_entry(const DevProblem& P, const Shared& sh, Row& R, uint32_t j, bool fresh) {
+  const PodEntry pe = sh.vc.ent[j];
+  // (two instantiations instead of one pointer select: a pointer that may be LDS or global memory compiles to flat loads)
+  if (pe.bits != 0xFFFF) row_merge_entry_from(P, sh, R, j, fresh, pe, sh.vc.ebits + pe.bits);
+  else row_merge_entry_from(P, sh, R, j, fresh, pe, P.rs_bits + P.e_bits[pe.e]);
+}
+
 // Step 5 for ONE active resource: requests including the pod, and the fit threshold they select.
 KG_HD void row_merge_resource(const DevProblem& P, const Shared& sh, Row& R, int r, bool fresh) {
   const int64_t add = sh.preq[r];
@@ -477,8 +483,8 @@ KG_HD void row_merge_resource(const DevProblem& P, const Shared& sh, Row& R, int
   const int64_t nr = R.req[r] + add;
   R.req[r] = nr;
   if (nr > 0) {
-    const int64_t* tv = sh.thr_lds ? sh.thr_val + sh.thr_base[r] : P.thr_val + sh.a_thr_off[r];
-    R.thr_idx[r] = thr_lookup_ge(tv, (int)sh.a_thr_n[r], nr);
+    R.thr_idx[r] = sh.thr_lds ? thr_lookup_ge(sh.thr_val + sh.thr_base[r], (int)sh.a_thr_n[r], nr)
+                              : thr_lookup_ge(P.thr_val + sh.a_thr_off[r], (int)sh.a_thr_n[r], nr);
     atomic_or_u32(&R.thr_use, 1u << r);
   }
 }
@@ -535,7 +541,8 @@ KG_HD uint64_t row_word(const DevProblem& P, const SimState& S, const Shared& sh
     if (!((R.ent_changed >> j) & 1)) continue;
     const PodEntry pe = sh.vc.ent[j];
     if (pe.spec >= 0) continue;
-    uint64_t f = sh.tw_lds ? sh.eam[j][w] : P.e_amask[(size_t)pe.e * P.TW + w];
+    uint64_t f;
+    if (sh.tw_lds) { f = sh.eam[j][w]; KG_OPAQUE64(f); } else f = P.e_amask[(size_t)pe.e * P.TW + w];
     if ((R.ent_dne_ok >> j) & 1) f |= P.kU[(size_t)pe.slot * P.TW + w];
     m &= f;
   }
@@ -601,7 +608,8 @@ KG_HD uint64_t row_word(const DevProblem& P, const SimState& S, const Shared& sh
     for (int r = 0; r < KG_MAXR; ++r) {
       const bool use = r < P.R && ((R.thr_use >> r) & 1);
       const bool none = use && R.thr_idx[r] >= (int)sh.a_thr_n[r];
-      tm[r] = !use ? ~0ull : (none ? 0ull : P.thr_mask[((size_t)sh.a_thr_off[r] + (none ? 0 : R.thr_idx[r])) * P.TW + w]);
+      const uint64_t v = P.thr_mask[((size_t)sh.a_thr_off[r] + ((use && !none) ? R.thr_idx[r] : 0)) * P.TW + w];  // unconditional load
+      tm[r] = !use ? ~0ull : (none ? 0ull : v);
     }
 #pragma unroll
     for (int r = 0; r < KG_MAXR; ++r) m &= tm[r];
@@ -610,10 +618,18 @@ KG_HD uint64_t row_word(const DevProblem& P, const SimState& S, const Shared& sh
   // hasOffering
   if (off_use) {
     uint64_t f = 0;
-    for (int z = 0; z < P.n_zone_vals; ++z) {
-      if (!((zmask >> z) & 1)) continue;
-      for (int ct = 0; ct < P.n_ct_vals; ++ct)
-        if ((ctmask >> ct) & 1) f |= sh.off_lds ? sh.offm[z * P.n_ct_vals + ct][w] : P.offmask[((size_t)z * 4 + ct) * P.TW + w];
+    if (sh.off_lds) {
+      for (int z = 0; z < P.n_zone_vals; ++z) {
+        if (!((zmask >> z) & 1)) continue;
+        for (int ct = 0; ct < P.n_ct_vals; ++ct)
+          if ((ctmask >> ct) & 1) f |= sh.offm[z * P.n_ct_vals + ct][w];
+      }
+    } else {
+      for (int z = 0; z < P.n_zone_vals; ++z) {
+        if (!((zmask >> z) & 1)) continue;
+        for (int ct = 0; ct < P.n_ct_vals; ++ct)
+          if ((ctmask >> ct) & 1) f |= P.offmask[((size_t)z * 4 + ct) * P.TW + w];
+      }
     }
     m &= f;
   }
@@ -822,7 +838,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
       if (tid == 0) {
         if (sh.qlen == 0) sh.done = 1;
         else {
-          const uint4 qe = ((const uint4*)S.queue)[sh.qhead % QCAP];
+          const uint4 qe = ((const KG_GLOBAL uint4*)S.queue)[sh.qhead % QCAP];
           if (qe.z == sh.epoch && qe.w == sh.qlen) sh.done = 1;
           else {
             sh.pod = qe.x;
@@ -846,7 +862,8 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
         const int r = tid - (NT - KG_MAXR);
         sh.preq[r] = r < P.R ? P.preq[(size_t)sh.pod * P.R + r] : 0;
       }
-      if (tid >= NT / 2 && tid < NT / 2 + P.TW && P.TW <= KG_TWLDS) sh.podmask[tid - NT / 2] = P.podmask[(size_t)sh.variant * P.TW + (tid - NT / 2)];
+      if (tid >= NT / 2 && tid < NT / 2 + KG_TWLDS && P.TW <= KG_TWLDS)  // zero-padded: the prefilter ANDs all KG_TWLDS words
+        sh.podmask[tid - NT / 2] = tid - NT / 2 < P.TW ? P.podmask[(size_t)sh.variant * P.TW + (tid - NT / 2)] : 0;
       if (tid >= 96 && tid < 96 + KG_MAXE * KG_TWLDS && P.TW <= KG_TWLDS) {
         // e_amask rows of the pod's requirement entries (entry ids straight from the global record: same round trip)
         const uint32_t j = (uint32_t)(tid - 96) / KG_TWLDS, w = (uint32_t)(tid - 96) % KG_TWLDS;
@@ -913,15 +930,19 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
               bool ok = true;
               const uint32_t np_ = S.c_npods[c], st_ = S.c_stamp[c];
               if (!STATS) {
-                // every load below is independent: one round trip to memory for the whole test
+                // every load below is independent and UNCONDITIONAL (a load under a branch is not issued before the
+                // previous one has returned): one round trip to memory for the whole test
                 const uint32_t tm = S.c_tmpl[c];
                 int64_t hd[KG_MAXR];
 #pragma unroll
-                for (int r = 0; r < KG_MAXR; ++r) hd[r] = (r < P.R && sh.preq[r] != 0) ? S.c_head[(size_t)r * P.Cmax + c] : 0;
+                for (int r = 0; r < KG_MAXR; ++r) hd[r] = S.c_head[(size_t)(r < P.R ? r : 0) * P.Cmax + c];
                 uint64_t any = 0;
                 if (P.TW <= KG_TWLDS) {
+                  uint64_t mk[KG_TWLDS];
 #pragma unroll
-                  for (int w = 0; w < KG_TWLDS; ++w) if (w < P.TW) any |= S.c_mask[(size_t)w * P.Cmax + c] & sh.podmask[w];
+                  for (int w = 0; w < KG_TWLDS; ++w) mk[w] = S.c_mask[(size_t)(w < P.TW ? w : 0) * P.Cmax + c];
+#pragma unroll
+                  for (int w = 0; w < KG_TWLDS; ++w) any |= mk[w] & sh.podmask[w];
                 } else {
                   const uint64_t* pm = P.podmask + (size_t)sh.variant * P.TW;
                   for (int w = 0; w < P.TW; ++w) any |= S.c_mask[(size_t)w * P.Cmax + c] & pm[w];
@@ -1041,16 +1062,18 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
               const uint32_t c = sh.sorted[lo + gi];
               if (TWP == 16) {
                 // straight-line, independent loads (Ka <= 32 metas, Wa <= 64 words, R <= 8 requests): one round trip
-                const uint32_t m0 = w < (uint32_t)P.Ka ? S.c_meta[(size_t)w * P.Cmax + c] : 0;
-                const uint32_t m1 = w + 16 < (uint32_t)P.Ka ? S.c_meta[(size_t)(w + 16) * P.Cmax + c] : 0;
+                // (unconditional loads from clamped rows, selected afterwards)
+                const uint32_t Ka1 = P.Ka > 0 ? (uint32_t)P.Ka - 1 : 0, Wa1 = P.Wa > 0 ? (uint32_t)P.Wa - 1 : 0, R1 = P.R > 0 ? (uint32_t)P.R - 1 : 0;
+                const uint32_t m0 = S.c_meta[(size_t)(w < Ka1 ? w : Ka1) * P.Cmax + c];
+                const uint32_t m1 = S.c_meta[(size_t)(w + 16 < Ka1 ? w + 16 : Ka1) * P.Cmax + c];
                 uint64_t b[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) b[k] = w + 16 * k < (uint32_t)P.Wa ? S.c_bits[(size_t)(w + 16 * k) * P.Cmax + c] : 0;
-                const int64_t rq = w < (uint32_t)P.R ? S.c_req[(size_t)w * P.Cmax + c] : 0;
-                R.meta[w] = m0; R.meta[w + 16] = m1;
+                for (int k = 0; k < 4; ++k) b[k] = S.c_bits[(size_t)(w + 16 * k < Wa1 ? w + 16 * k : Wa1) * P.Cmax + c];
+                const int64_t rq = S.c_req[(size_t)(w < R1 ? w : R1) * P.Cmax + c];
+                R.meta[w] = w < (uint32_t)P.Ka ? m0 : 0; R.meta[w + 16] = w + 16 < (uint32_t)P.Ka ? m1 : 0;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) R.bits[w + 16 * k] = b[k];
-                if (w < KG_MAXR) R.req[w] = rq;
+                for (int k = 0; k < 4; ++k) R.bits[w + 16 * k] = w + 16 * k < (uint32_t)P.Wa ? b[k] : 0;
+                if (w < KG_MAXR) R.req[w] = w < (uint32_t)P.R ? rq : 0;
               } else {
                 for (int a = (int)w; a < P.Ka; a += (int)TWP) R.meta[a] = S.c_meta[(size_t)a * P.Cmax + c];
                 for (int i = (int)w; i < P.Wa; i += (int)TWP) R.bits[i] = S.c_bits[(size_t)i * P.Cmax + c];
@@ -1065,6 +1088,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
             }
           }
           KG_SYNC();
+          KG_T(8);
         }
         // merge the pod: one thread per requirement entry, one per resource
         KG_FOR_THREADS(tid, NT) {
@@ -1082,6 +1106,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
           }
           KG_SYNC();
         }
+        KG_T(9);
         // instance-type filter: one thread per 64-type word
         KG_FOR_THREADS(tid, NT) {
           const uint32_t gi = (uint32_t)tid / TWP, w = (uint32_t)tid % TWP;
@@ -1094,6 +1119,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
           }
         }
         KG_SYNC();
+        KG_T(10);
         KG_FOR_THREADS(tid, NT) {
           if (tid == 0) {
             sh.need_refresh = 0;
@@ -1116,6 +1142,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
           }
         }
         KG_SYNC();
+        KG_T(11);
         if (sh.need_refresh) {
           // tighten the headroom of false survivors
           KG_FOR_THREADS(tid, NT) {
@@ -1259,7 +1286,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
           qe.y = sh.variant;
           qe.z = sh.epoch; qe.w = sh.qlen;  // lastLen[pod] = len(queue) after the push
         }
-        ((uint4*)S.queue)[(sh.qhead + sh.qlen - 1) % QCAP] = qe;
+        ((KG_GLOBAL uint4*)S.queue)[(sh.qhead + sh.qlen - 1) % QCAP] = qe;
       }
     }
     KG_SYNC();
