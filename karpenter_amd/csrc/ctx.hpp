@@ -13,7 +13,7 @@ struct kg_ctx {
   kg_stats stats{};
   bool collect_timers = false;
   int sim_block_threads = 256;  // workgroup size of k_solve for consolidation batches (one workgroup per simulation)
-  int block_threads = 512;  // workgroup size of k_solve (256, 512 or 1024)
+  int block_threads = 256;  // workgroup size of k_solve (256, 512 or 1024): 256 measured best (one wave per SIMD)
   bool collect_stats = true;  // maintain the reference-visit counters (exact; costs an extra pass per placement)
   std::mutex mu;
   uint32_t kHostname, kZone, kCT, kZid, kNodePool, kInstanceType;

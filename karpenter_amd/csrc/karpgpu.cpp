@@ -277,7 +277,7 @@ struct Compiled {
   uint32_t qcap = 0;
   std::vector<uint32_t> queue_order, pod_variant0;  // pods in Queue order; initial variant of every pod
   size_t o_nreq, o_creq, o_chead, o_chstamp, o_cmask, o_cbits, o_cmeta, o_cnpods, o_ctmpl, o_order, o_remaining, o_gcount, o_gdom, o_gpos, o_hcount, o_hpos, o_queue,
-      o_podkind, o_excl, o_podindex, o_podreason, o_scratch, o_header, o_counters, o_nqueue;
+      o_podkind, o_excl, o_podindex, o_podreason, o_scratch, o_ordg, o_header, o_counters, o_nqueue;
   ~Compiled() {
     hal::dfree(prob_dev.ptr);
     hal::dfree(state_dev.ptr);
@@ -1059,7 +1059,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   Arena SA;
   std::vector<int64_t> remaining0(tmpl_limits0);
   std::vector<uint32_t> header(16, 0), nqueue{(uint32_t)P};
-  std::vector<uint64_t> counters(32, 0);
+  std::vector<uint64_t> counters(64, 0);
   C.o_nreq = SA.add(nreq0);
   C.o_creq = SA.reserve((size_t)std::max(R, 1) * Cmax * 8);
   C.o_chead = SA.reserve((size_t)std::max(R, 1) * Cmax * 8);
@@ -1085,6 +1085,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   C.o_podreason = SA.reserve((size_t)PR * 4);
   C.o_excl = SA.reserve((size_t)NW * 8);
   C.o_scratch = SA.reserve((size_t)(TW + 1) * Cmax * 8);
+  C.o_ordg = SA.reserve((size_t)2 * Cmax * 8);
   C.o_header = SA.add(header);
   C.o_counters = SA.add(counters);
   C.o_nqueue = SA.add(nqueue);
@@ -1113,7 +1114,7 @@ static SimState sim_at(const Compiled& C, uint8_t* base) {
   St.hcount = (int32_t*)sptr(C.o_hcount); St.hpos = (int32_t*)sptr(C.o_hpos); St.queue = (uint32_t*)sptr(C.o_queue); St.pod_kind = (uint8_t*)sptr(C.o_podkind);
   St.pod_index = (int32_t*)sptr(C.o_podindex); St.pod_reason = (uint32_t*)sptr(C.o_podreason); St.scratch = (uint64_t*)sptr(C.o_scratch);
   St.header = (uint32_t*)sptr(C.o_header); St.counters = (uint64_t*)sptr(C.o_counters);
-  St.excl = (const uint64_t*)sptr(C.o_excl);
+  St.excl = (const uint64_t*)sptr(C.o_excl); St.ordg = (unsigned long long*)sptr(C.o_ordg);
   St.n_shared = (uint32_t)C.P; St.pod_base = 0; St.qcap = C.qcap;
   return St;
 }
@@ -1232,7 +1233,7 @@ int32_t kg_set_collect_stats(kg_ctx* ctx, int32_t enabled) {
   std::lock_guard<std::mutex> lk(ctx->mu);
   ctx->collect_stats = (enabled & 1) != 0;
   ctx->collect_timers = (enabled & 2) != 0;
-  ctx->block_threads = (enabled & 4) ? 1024 : ((enabled & 8) ? 256 : 512);  // debugging aid: per-phase ticks of k_solve printed to stderr
+  ctx->block_threads = (enabled & 4) ? 1024 : ((enabled & 8) ? 512 : 256);  // debugging aid: per-phase ticks of k_solve printed to stderr
   return KG_OK;
 }
 
@@ -1374,19 +1375,25 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
   std::vector<uint8_t> pod_kind(std::max(P, 1));
   std::vector<int32_t> pod_index(std::max(P, 1));
   std::vector<uint32_t> pod_reason(std::max(P, 1)), header(16);
-  std::vector<uint64_t> counters(32);
+  std::vector<uint64_t> counters(64);
   auto sp = [&](size_t off) { return (uint8_t*)C->state_dev.ptr + off; };
   hal::d2h(pod_kind.data(), sp(C->o_podkind), P);
   hal::d2h(pod_index.data(), sp(C->o_podindex), (size_t)P * 4);
   hal::d2h(pod_reason.data(), sp(C->o_podreason), (size_t)P * 4);
   hal::d2h(header.data(), sp(C->o_header), 64);
-  hal::d2h(counters.data(), sp(C->o_counters), 256);
+  hal::d2h(counters.data(), sp(C->o_counters), 512);
   if (ctx->collect_timers) {
-    static const char* names[] = {"pop+ctx", "nodes", "prefilter", "sort", "eval.rest", "stats", "commit", "newclaim/relax", "eval.load", "eval.merge", "eval.word", "eval.pick"};
-    for (int i = 0; i < 12; ++i) fprintf(stderr, "[kg timers] %-15s %10.3f ms\n", names[i], counters[8 + i] / 1e5);
+    static const char* names[] = {"pop+ctx", "nodes", "prefilter", "load rows", "merge(+topology)", "type filter", "pick", "commit", "fresh setup", "relax"};
+    for (int i = 0; i < 10; ++i) fprintf(stderr, "[kg timers] %-15s %10.3f ms\n", names[i], counters[8 + i] / 1e5);
+    static const char* sub[] = {"pf: entry", "pf: loads+test", "pf: ballot+ctx fetch", "pf: barrier", "load: select", "load: loads", "merge: thread 0", "filter: thread 0", "pick: body", "commit: body"};
+    for (int i = 0; i < 10; ++i) fprintf(stderr, "[kg timers]   sub %-20s %10.3f ms\n", sub[i], counters[32 + i] / 1e5);
     fprintf(stderr, "[kg timers] shader clock %.0f MHz over the launch\n", counters[25] ? counters[24] / (counters[25] / 100.0) : 0.0);
     fprintf(stderr, "[kg timers] probes (ns each): barrier %.0f, dependent global load %.0f, LDS store+2 barriers+LDS load %.0f, global store+barrier %.0f\n",
             counters[26] * 10.0 / 1000, counters[27] * 10.0 / 1000, counters[28] * 10.0 / 1000, counters[29] * 10.0 / 1000);
+    fprintf(stderr, "[kg timers] probes (ns each): chain over 256 KiB first walk %.0f, second walk %.0f, store->load same line %.0f\n",
+            counters[60] * 10.0 / 2048, counters[61] * 10.0 / 2048, counters[62] * 10.0 / 1000);
+    fprintf(stderr, "[kg timers] probes (ns each): round trip of 24 independent loads per lane: one wave %.0f, all waves %.0f, all waves scattered lanes %.0f\n",
+            counters[56] * 10.0 / 200, counters[57] * 10.0 / 200, counters[58] * 10.0 / 200);
     fprintf(stderr, "[kg timers] survivors %llu rounds %llu false_pos %llu passes %llu\n", (unsigned long long)counters[20],
             (unsigned long long)counters[21], (unsigned long long)counters[22], (unsigned long long)counters[23]);
   }

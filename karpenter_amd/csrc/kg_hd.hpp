@@ -18,6 +18,8 @@
 #define KG_SYNC() ((void)0)
 #define KG_GLOBAL
 #define KG_OPAQUE64(x) ((void)0)
+#define KG_UNI(x) (x)
+#define KG_UNI64(x) (x)
 struct alignas(16) uint4 { uint32_t x, y, z, w; };
 namespace kg {
 inline void atomic_min_u32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
@@ -27,6 +29,11 @@ inline uint32_t atomic_inc_u32(uint32_t* p) { return (*p)++; }
 inline void atomic_or_u32(uint32_t* p, uint32_t v) { *p |= v; }
 inline void atomic_add_u64(unsigned long long* p, unsigned long long v) { *p += v; }
 inline unsigned long long now_ticks() { return 0; }
+// word `tid / 64` of slots <- the predicate of the 64 threads tid belongs to (the emulation runs them in ascending order)
+inline void wave_ballot_store(unsigned long long* slots, int tid, bool pred) {
+  if ((tid & 63) == 0) slots[tid >> 6] = 0;
+  if (pred) slots[tid >> 6] |= 1ull << (tid & 63);
+}
 inline int popc64(uint64_t x) { return __builtin_popcountll(x); }
 inline int ctz64(uint64_t x) { return __builtin_ctzll(x); }
 }  // namespace kg
@@ -46,7 +53,15 @@ inline int ctz64(uint64_t x) { return __builtin_ctzll(x); }
 #endif
 // keeps the compiler from merging an LDS load and a global load of two branches into one flat load behind a pointer select
 #define KG_OPAQUE64(x) asm volatile("" : "+v"(x))
+// A value every thread of the workgroup computes identically (read from the same LDS / global word): tell the compiler,
+// so that it lives in a scalar register and steers scalar branches instead of exec-mask bookkeeping.
+#define KG_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#define KG_UNI64(x) kg::uni64((unsigned long long)(x))
 namespace kg {
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
 // workgroup-shared (LDS) minimum
 __device__ __forceinline__ void atomic_min_u32(uint32_t* p, uint32_t v) { atomicMin(p, v); }
 __device__ __forceinline__ void atomic_min_u64(unsigned long long* p, unsigned long long v) { atomicMin(p, v); }
@@ -55,6 +70,11 @@ __device__ __forceinline__ uint32_t atomic_inc_u32(uint32_t* p) { return atomicA
 __device__ __forceinline__ void atomic_or_u32(uint32_t* p, uint32_t v) { atomicOr(p, v); }
 __device__ __forceinline__ void atomic_add_u64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
 __device__ __forceinline__ unsigned long long now_ticks() { return wall_clock64(); }  // 100 MHz
+// word `tid / 64` of slots <- the wave's ballot (every thread of the workgroup must call it)
+__device__ __forceinline__ void wave_ballot_store(unsigned long long* slots, int tid, bool pred) {
+  const unsigned long long b = __ballot(pred);
+  if ((tid & 63) == 0) slots[tid >> 6] = b;
+}
 __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
 __device__ __forceinline__ int ctz64(uint64_t x) { return __ffsll((unsigned long long)x) - 1; }
 }  // namespace kg

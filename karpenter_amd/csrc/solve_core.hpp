@@ -38,8 +38,9 @@ constexpr int KG_MAXSPEC = 6;   // "special" 1-word keys: zone, capacity-type, z
 constexpr int KG_MAXLIST = 8;   // topology groups consulted for one pod
 constexpr int KG_EBITS = 32;    // requirement-value words of one pod staged in LDS
 constexpr int KG_THR_LDS = 1024;  // fit-threshold values staged in LDS
-constexpr int KG_MAXSURV = 1024;  // prefilter survivors handled per round
+constexpr int KG_ORD = 2048;      // in-flight NodeClaims whose scan order is kept in LDS (global memory beyond)
 constexpr int KG_MAXGP = 32;      // NodeClaims evaluated exactly per pass
+constexpr int KG_GP0 = 8;         // ... in the first pass over a chunk of the scan order
 constexpr int KG_ROWW = 64;       // requirement-value words of one claim row
 constexpr int KG_TWLDS = 16;      // option-mask words (<= 1024 instance types) for the tables staged in LDS
 constexpr int KG_SPV = 8;         // values per special key whose value->types rows are staged in LDS
@@ -208,6 +209,7 @@ struct SimState {
   KG_GLOBAL uint32_t* pod_reason; // [P]
   KG_GLOBAL uint64_t* scratch;  // [TW+1][Cmax] candidate option masks of the survivors; row TW: per-claim visit statistic
   KG_GLOBAL uint32_t* header;   // [16]: 0 nclaims, 1 relaxations, 2-5 the claim touched after the last sort (id, old pods, old stamp, new)
+  KG_GLOBAL unsigned long long* ordg; // [2][Cmax] scan order beyond KG_ORD claims (same packing as Shared::ord)
   const KG_GLOBAL uint64_t* excl; // [NW] existing nodes left out of this simulation (consolidation candidates)
   uint32_t n_shared, pod_base, qcap;  // pods [0,n_shared) and [pod_base, ...) take part; result rows are local indices
   KG_GLOBAL uint64_t* counters; // [32]: 8.. phase timers and scan statistics when stats&2; [0..3]: visited_existing, visited_claims, visited_claim_types, new_claim_scans
@@ -216,7 +218,7 @@ struct SimState {
 // One evaluation group's working copy of a NodeClaim (LDS): the claim's requirement row is loaded here, the pod is
 // merged into it in place (NodeClaim.Add steps 3-5), and the winner's copy is what the commit writes back.
 struct Row {
-  uint32_t c, tmpl, ok, reason, feas, tv;
+  uint32_t c, tmpl, ok, reason, pos, tv;  // pos: the claim's place in the scan order
   uint32_t npods, stamp;
   uint32_t ent_changed, ent_dne_ok, sp_changed, thr_use, has_topo, pad_;
   int32_t thr_idx[KG_MAXR];
@@ -226,17 +228,25 @@ struct Row {
   uint64_t bits[KG_ROWW];          // requirement value bits, Wa words
 };
 
-struct Shared {
-  uint32_t pod, variant, best, nclaims, qhead, qlen, epoch, done, placed, seq, reason;
-  uint32_t last_c, last_npods, last_stamp, last_new;  // the one claim touched since the reference's last sort.Slice
-  uint32_t nsurv, scan_base, pass_lo, winner, win_g, thr_lds, fresh_lim, need_refresh;
-  uint32_t stage, tnext, result, st_vis;
-  unsigned long long bestkey, st_types;
+// Everything one Queue.Pop brings into LDS: the pod variant's precompiled record, the pod's requests, its own type mask
+// (prefilter) and the type masks of its requirement entries.
+struct PodCtx {
   int64_t preq[KG_MAXR];
   VariantCtx vc;
-  uint64_t podmask[KG_TWLDS];       // the pod variant's own type mask (prefilter)
+  uint64_t podmask[KG_TWLDS];
   uint64_t eam[KG_MAXE][KG_TWLDS];  // e_amask rows of the pod's requirement entries
-  uint32_t cur_epoch, cur_len, tw_lds, off_lds, stw_lds;
+};
+static_assert(sizeof(PodCtx) % 8 == 0, "PodCtx is copied as 64-bit words");
+
+struct Shared {
+  uint32_t pod, variant, best, reason;
+  uint32_t thr_lds, tw_lds, off_lds, stw_lds;
+  uint32_t fresh_lim[2];            // per template attempt (alternating): some instance type is within the limits
+  uint32_t feas[2], mvf[2];         // per pass (alternating): rows whose option mask stays non-empty / rows failing minValues
+  uint32_t endk, need;              // end of the winner's pod-count group in the scan order; resources the pod requests
+  unsigned long long ball[16];      // prefilter ballots of the current chunk of scan positions, one word per wave
+  PodCtx pc;                        // the pod being placed
+  PodCtx nx;                        // the next pod of the queue, fetched while the current one is placed
   uint64_t offm[KG_OFFROWS][KG_TWLDS];          // offering masks [zone * n_ct + ct]
   uint64_t stw[KG_MAXSPEC][KG_SPV][KG_TWLDS];   // value->types rows of the special keys
   // small problem tables
@@ -246,14 +256,11 @@ struct Shared {
   uint32_t thr_base[KG_MAXR];
   uint32_t a_thr_off[KG_MAXR], a_thr_n[KG_MAXR], a_cthr_off[KG_MAXR], a_cthr_n[KG_MAXR], a_res[KG_MAXR];
   int64_t thr_val[KG_THR_LDS];
-  // prefilter survivors of the current round
-  uint32_t surv[KG_MAXSURV];             // claim ids, in arrival order
-  unsigned long long skey[KG_MAXSURV];   // their scan-order keys
-  uint32_t sorted[KG_MAXSURV];           // claim ids in scan order
-  uint32_t srank[KG_MAXSURV];            // rank accumulators
+  // the in-flight NodeClaims in scan order (the reference's sorted slice), double-buffered: pod count << 32 | claim id
+  unsigned long long ord[2][KG_ORD];
   Row rows[KG_MAXGP];                    // evaluation groups of the current pass
-  Row wrow;                              // the best NodeClaim so far when the scan needs more than one round
 };
+
 
 // ------------------------------------------------------------------ requirement algebra
 struct SReq {  // a requirement on a 1-word slot
@@ -333,7 +340,7 @@ KG_HD int first_by_rank(const DevProblem& P, int sp, uint64_t m) {
 KG_HD TopoOut topo_small(const DevProblem& P, const SimState& S, const Group& g, uint32_t gi, bool self, uint64_t podDom, uint64_t nodeDom) {
   const int sp = g.spec;
   const uint64_t gd = S.gdom[gi];
-  const int32_t* cnt = S.gcount + (size_t)gi * 64;
+  const auto* cnt = S.gcount + (size_t)gi * 64;
   TopoOut out{false, 0};
   if (g.type == TG_SPREAD) {
     int32_t mn = 0x7FFFFFFF;
@@ -392,7 +399,7 @@ KG_HD void record_small(const SimState& S, uint32_t gi, int d) {
   S.gpos[gi] |= 1ull << d;
 }
 KG_HD void record_host(const SimState& S, const DevProblem& P, const Group& g, uint32_t h) {
-  int32_t* p = &S.hcount[(size_t)g.hidx * P.H + h];
+  auto* p = &S.hcount[(size_t)g.hidx * P.H + h];
   if (*p == 0) S.hpos[g.hidx] += 1;
   *p += 1;
 }
@@ -470,20 +477,20 @@ KG_HD void row_merge_entry_from(const DevProblem& P, const Shared& sh, Row& R, u
 }
 
 KG_HD void row_merge_entry(const DevProblem& P, const Shared& sh, Row& R, uint32_t j, bool fresh) {
-  const PodEntry pe = sh.vc.ent[j];
+  const PodEntry pe = sh.pc.vc.ent[j];
   // (two instantiations instead of one pointer select: a pointer that may be LDS or global memory compiles to flat loads)
-  if (pe.bits != 0xFFFF) row_merge_entry_from(P, sh, R, j, fresh, pe, sh.vc.ebits + pe.bits);
+  if (pe.bits != 0xFFFF) row_merge_entry_from(P, sh, R, j, fresh, pe, sh.pc.vc.ebits + pe.bits);
   else row_merge_entry_from(P, sh, R, j, fresh, pe, P.rs_bits + P.e_bits[pe.e]);
 }
 
 // Step 5 for ONE active resource: requests including the pod, and the fit threshold they select.
 KG_HD void row_merge_resource(const DevProblem& P, const Shared& sh, Row& R, int r, bool fresh) {
-  const int64_t add = sh.preq[r];
+  const int64_t add = sh.pc.preq[r];
   if (add == 0 && !fresh) return;
   const int64_t nr = R.req[r] + add;
   R.req[r] = nr;
   if (nr > 0) {
-    R.thr_idx[r] = sh.thr_lds ? thr_lookup_ge(sh.thr_val + sh.thr_base[r], (int)sh.a_thr_n[r], nr)
+    R.thr_idx[r] = KG_UNI(sh.thr_lds) ? thr_lookup_ge(sh.thr_val + sh.thr_base[r], (int)sh.a_thr_n[r], nr)
                               : thr_lookup_ge(P.thr_val + sh.a_thr_off[r], (int)sh.a_thr_n[r], nr);
     atomic_or_u32(&R.thr_use, 1u << r);
   }
@@ -494,9 +501,9 @@ KG_HD void row_topology(const DevProblem& P, const SimState& S, const Shared& sh
   const uint32_t hslot = P.N + R.c;
   for (int i = 0; i < P.nspec; ++i) R.topo[i] = ~0ull;
   uint32_t has_topo = 0;
-  for (uint32_t li = 0; li < sh.vc.nlist; ++li) {
-    const ListEntry le = sh.vc.lst[li].le;
-    const Group g = sh.vc.lst[li].g;
+  for (uint32_t li = 0; li < sh.pc.vc.nlist; ++li) {
+    const ListEntry le = sh.pc.vc.lst[li].le;
+    const Group g = sh.pc.vc.lst[li].g;
     const bool self = le.flags & LF_SELF;
     if (g.spec == 0xFF) {
       if (!topo_host(S, P, g, self, hslot)) { R.ok = 0; R.reason |= 4; return; }
@@ -535,14 +542,14 @@ KG_HD void row_topology(const DevProblem& P, const SimState& S, const Shared& sh
 // Step 6: filterInstanceTypesByRequirements in type-mask space: word w of the claim's remaining options after the pod.
 KG_HD uint64_t row_word(const DevProblem& P, const SimState& S, const Shared& sh, const Row& R, bool fresh, int w) {
   uint64_t m = S.c_mask[(size_t)w * P.Cmax + R.c];
-  const uint32_t ne = sh.vc.ne;
+  const uint32_t ne = sh.pc.vc.ne;
   // pod entries on ordinary keys
   for (uint32_t j = 0; j < ne; ++j) {
     if (!((R.ent_changed >> j) & 1)) continue;
-    const PodEntry pe = sh.vc.ent[j];
+    const PodEntry pe = sh.pc.vc.ent[j];
     if (pe.spec >= 0) continue;
     uint64_t f;
-    if (sh.tw_lds) { f = sh.eam[j][w]; KG_OPAQUE64(f); } else f = P.e_amask[(size_t)pe.e * P.TW + w];
+    if (KG_UNI(sh.tw_lds)) { f = sh.pc.eam[j][w]; KG_OPAQUE64(f); } else f = P.e_amask[(size_t)pe.e * P.TW + w];
     if ((R.ent_dne_ok >> j) & 1) f |= P.kU[(size_t)pe.slot * P.TW + w];
     m &= f;
   }
@@ -555,7 +562,7 @@ KG_HD uint64_t row_word(const DevProblem& P, const SimState& S, const Shared& sh
       uint64_t f = P.e_amask[(size_t)e * P.TW + w];
       bool shared = false, dne_ok = false;
       for (uint32_t j = 0; j < ne; ++j)
-        if (sh.vc.ent[j].slot == a) { shared = true; dne_ok = (R.ent_dne_ok >> j) & 1; }
+        if (sh.pc.vc.ent[j].slot == a) { shared = true; dne_ok = (R.ent_dne_ok >> j) & 1; }
       if (!shared) {
         const uint64_t* tb = P.rs_bits + P.e_bits[e];
         bool anyb = false;
@@ -578,7 +585,7 @@ KG_HD uint64_t row_word(const DevProblem& P, const SimState& S, const Shared& sh
     if (changed && present) {
       uint64_t f = P.kN[(size_t)a * P.TW + w];
       if (op_neg(opclass(sp.meta & RM_COMPL, sp.word != 0))) f |= P.kU[(size_t)a * P.TW + w];
-      if (sh.stw_lds) {
+      if (KG_UNI(sh.stw_lds)) {
         for (uint64_t mm = hm & ((1ull << KG_SPV) - 1); mm; mm &= mm - 1) f |= sh.stw[i][ctz64(mm)][w];
       } else {
         const int nv = P.ktwv_n[a];
@@ -608,7 +615,8 @@ KG_HD uint64_t row_word(const DevProblem& P, const SimState& S, const Shared& sh
     for (int r = 0; r < KG_MAXR; ++r) {
       const bool use = r < P.R && ((R.thr_use >> r) & 1);
       const bool none = use && R.thr_idx[r] >= (int)sh.a_thr_n[r];
-      const uint64_t v = P.thr_mask[((size_t)sh.a_thr_off[r] + ((use && !none) ? R.thr_idx[r] : 0)) * P.TW + w];  // unconditional load
+      uint64_t v = 0;
+      if (r < P.R) v = P.thr_mask[((size_t)sh.a_thr_off[r] + ((use && !none) ? R.thr_idx[r] : 0)) * P.TW + w];  // under a scalar condition only
       tm[r] = !use ? ~0ull : (none ? 0ull : v);
     }
 #pragma unroll
@@ -618,7 +626,7 @@ KG_HD uint64_t row_word(const DevProblem& P, const SimState& S, const Shared& sh
   // hasOffering
   if (off_use) {
     uint64_t f = 0;
-    if (sh.off_lds) {
+    if (KG_UNI(sh.off_lds)) {
       for (int z = 0; z < P.n_zone_vals; ++z) {
         if (!((zmask >> z) & 1)) continue;
         for (int ct = 0; ct < P.n_ct_vals; ++ct)
@@ -687,7 +695,7 @@ KG_HD bool row_compatible_rs(const DevProblem& P, const Shared& sh, const Row& R
 
 // Topology.Record for a pod placed on the claim of row R (after the commit of its requirements)
 KG_HD void row_record_topology(const DevProblem& P, const SimState& S, const Shared& sh, const Row& R) {
-  const Variant& v = sh.vc.v;
+  const Variant& v = sh.pc.vc.v;
   const uint32_t hslot = P.N + R.c;
   for (uint32_t li = 0; li < v.record_cnt; ++li) {
     const ListEntry le = P.lists[v.record_off + li];
@@ -724,18 +732,18 @@ KG_HD void claim_refresh_head(const DevProblem& P, const SimState& S, const Shar
 // ------------------------------------------------------------------ ExistingNode.Add for node n (scan position)
 template <bool COMMIT>
 KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, uint32_t n, uint32_t* reason) {
-  const Variant& v = sh.vc.v;
+  const Variant& v = sh.pc.vc.v;
   const uint32_t wi = n >> 6, bi = n & 63;
   if ((S.excl[wi] >> bi) & 1) return false;  // a candidate of this simulation: not a state node
   if (!((P.ntol[(size_t)v.tolset * P.NW + wi] >> bi) & 1)) { *reason |= 1; return false; }
   // resources first (cheap reject), as upstream does
   for (int r = 0; r < P.R; ++r) {
-    if (sh.preq[r] != 0 && S.nreq[(size_t)r * P.N + n] + sh.preq[r] > P.navail[(size_t)r * P.N + n]) { *reason |= 64; return false; }
+    if (sh.pc.preq[r] != 0 && S.nreq[(size_t)r * P.N + n] + sh.pc.preq[r] > P.navail[(size_t)r * P.N + n]) { *reason |= 64; return false; }
   }
   if (!((P.nlab[(size_t)v.rs * P.NW + wi] >> bi) & 1)) { *reason |= 2; return false; }
-  for (uint32_t li = 0; li < sh.vc.nlist; ++li) {
-    const ListEntry le = sh.vc.lst[li].le;
-    const Group g = sh.vc.lst[li].g;
+  for (uint32_t li = 0; li < sh.pc.vc.nlist; ++li) {
+    const ListEntry le = sh.pc.vc.lst[li].le;
+    const Group g = sh.pc.vc.lst[li].g;
     const bool self = le.flags & LF_SELF;
     if (g.spec == 0xFF) {
       if (!topo_host(S, P, g, self, n)) { *reason |= 4; return false; }
@@ -748,7 +756,7 @@ KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, u
     if (!o.ok || !((o.opts >> d) & 1)) { *reason |= 4; return false; }
   }
   if (COMMIT) {
-    for (int r = 0; r < P.R; ++r) if (sh.preq[r] != 0) S.nreq[(size_t)r * P.N + n] += sh.preq[r];
+    for (int r = 0; r < P.R; ++r) if (sh.pc.preq[r] != 0) S.nreq[(size_t)r * P.N + n] += sh.pc.preq[r];
     for (uint32_t li = 0; li < v.record_cnt; ++li) {
       const ListEntry le = P.lists[v.record_off + li];
       const Group g = P.groups[le.g];
@@ -769,21 +777,69 @@ KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, u
 // row of a pod in the per-simulation result arrays
 KG_HD uint32_t pod_row(const SimState& S, uint32_t pod) { return pod < S.n_shared ? pod : pod - S.pod_base + S.n_shared; }
 
+// position of the n-th (0-based) set bit of b; b has more than n bits set
+KG_HD uint32_t nth_set_bit(uint64_t b, uint32_t n) {
+  uint32_t pos = 0;
+#pragma unroll
+  for (int s = 32; s; s >>= 1) {
+    const uint32_t pc = (uint32_t)popc64(b & ((1ull << s) - 1));
+    if (n >= pc) { n -= pc; b >>= s; pos += s; }
+  }
+  return pos;
+}
+
+// scan-order entry: pod count << 32 | claim id, in LDS while the claims fit, in global memory beyond
+KG_HD unsigned long long ord_get(const SimState& S, const Shared& sh, const DevProblem& P, bool lds, uint32_t buf, uint32_t p) {
+  unsigned long long v;
+  if (lds) { v = sh.ord[buf][p]; KG_OPAQUE64(v); } else v = S.ordg[(size_t)buf * P.Cmax + p];
+  return v;
+}
+KG_HD void ord_set(const SimState& S, Shared& sh, const DevProblem& P, bool lds, uint32_t buf, uint32_t p, unsigned long long v) {
+  if (lds) sh.ord[buf][p] = v; else S.ordg[(size_t)buf * P.Cmax + p] = v;
+}
+
+// one Queue.Pop's worth of pod context, global -> sh.nx (each thread moves its share; needs a barrier afterwards)
+template <int NT>
+KG_HD void ctx_fetch(const DevProblem& P, Shared& sh, int tid, uint32_t pod, uint32_t variant) {
+  const uint64_t* src = (const uint64_t*)(P.vctx + variant);
+  uint64_t* dst = (uint64_t*)&sh.nx.vc;
+  for (uint32_t i = tid; i < sizeof(VariantCtx) / 8; i += NT) dst[i] = src[i];
+  if (tid >= NT - KG_MAXR) {
+    const int r = tid - (NT - KG_MAXR);
+    sh.nx.preq[r] = r < P.R ? P.preq[(size_t)pod * P.R + r] : 0;
+  }
+  if (tid >= NT / 2 && tid < NT / 2 + KG_TWLDS && P.TW <= KG_TWLDS)  // zero-padded: the prefilter ANDs all KG_TWLDS words
+    sh.nx.podmask[tid - NT / 2] = tid - NT / 2 < P.TW ? P.podmask[(size_t)variant * P.TW + (tid - NT / 2)] : 0;
+  if (tid >= 96 && tid < 96 + KG_MAXE * KG_TWLDS && P.TW <= KG_TWLDS) {
+    // e_amask rows of the pod's requirement entries (entry ids straight from the global record: same round trip)
+    const uint32_t j = (uint32_t)(tid - 96) / KG_TWLDS, w = (uint32_t)(tid - 96) % KG_TWLDS;
+    const VariantCtx* gv = P.vctx + variant;
+    if (j < gv->ne && w < (uint32_t)P.TW) sh.nx.eam[j][w] = P.e_amask[(size_t)gv->ent[j].e * P.TW + w];
+  }
+}
+
 // ------------------------------------------------------------------ one Solve by one workgroup
 // NT = threads in the workgroup.  `sh` lives in LDS.
 //
-// Barrier discipline: a value in LDS that steers uniform control flow (a loop condition, a branch around barriers) is
-// only ever written in a phase that is followed by a barrier AND is at least one barrier after the last uniform read
-// of it -- otherwise a fast wave overwrites it while a slow wave has not branched yet, and the waves' barrier counts
-// diverge.
+// Control state (queue ring, claim count, stage, winner) is UNIFORM: every thread keeps its own copy in registers and
+// derives it from the same LDS / global words, so no phase exists only to let thread 0 decide and broadcast.  Variables
+// declared outside the KG_FOR_THREADS bodies are such uniform values (the emulation keeps one copy of them).
+//
+// Barrier discipline: an LDS word that steers uniform control flow is only ever written in a phase that is followed by
+// a barrier AND is at least one barrier after the last uniform read of it -- otherwise a fast wave overwrites it while
+// a slow wave has not branched yet, and the waves' barrier counts diverge.  Words written once per pass alternate
+// between two slots for that reason (feas, mvf, fresh_lim).
 template <int NT>
 KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint32_t n_queue) {
   const bool STATS = (P.stats & 1) != 0;
   const bool TIMERS = (P.stats & 2) != 0;  // per-phase wall-clock ticks (100 MHz) of thread 0 into counters[8..]
   unsigned long long t_mark = 0;
 #define KG_T(i) do { if (TIMERS) { KG_FOR_THREADS(tid, NT) { if (tid == 0) { const unsigned long long n_ = now_ticks(); if (t_mark) S.counters[8 + (i)] += n_ - t_mark; t_mark = n_; } } } } while (0)
+  // (inside a phase body: thread 0's own progress, counters[32 + k])
+#define KG_ST(k) do { if (TIMERS && tid == 0) { const unsigned long long n_ = now_ticks(); if (t_mark) S.counters[32 + (k)] += n_ - t_mark; t_mark = n_; } } while (0)
   const uint32_t TWP = (uint32_t)P.TWP;      // threads per evaluation group (power of two >= max(TW, 16))
-  const uint32_t GP = (NT / TWP) < (uint32_t)KG_MAXGP ? (NT / TWP) : (uint32_t)KG_MAXGP;  // survivors evaluated per pass
+  const uint32_t GP = (NT / TWP) < (uint32_t)KG_MAXGP ? (NT / TWP) : (uint32_t)KG_MAXGP;  // claims evaluated per pass
+  static_assert(NT % 64 == 0 && NT / 64 <= 16, "one ballot word per wave");
   // ---- stage the small problem tables in LDS
   KG_FOR_THREADS(tid, NT) {
     if (tid < KG_MAXR) {
@@ -794,10 +850,10 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
   KG_SYNC();
   KG_FOR_THREADS(tid, NT) {
     if (tid == 0) {
-      sh.qhead = 0; sh.qlen = n_queue; sh.epoch = 1; sh.nclaims = S.header[0]; sh.done = 0; sh.seq = 0; sh.last_c = KG_NOIDX; sh.last_new = 0;
       uint32_t tot = 0;
       for (int r = 0; r < P.R; ++r) { sh.thr_base[r] = tot; tot += sh.a_thr_n[r]; }
       sh.thr_lds = tot <= (uint32_t)KG_THR_LDS;
+      sh.reason = 0; sh.endk = 0; sh.feas[0] = sh.feas[1] = 0; sh.mvf[0] = sh.mvf[1] = 0;
     }
     for (int a = tid; a < P.Ka; a += NT) { sh.aoff[a] = P.aoff[a]; sh.aw[a] = P.aw[a]; sh.slot2spec[a] = P.slot2spec[a]; }
     for (int i = tid; i < P.nspec; i += NT) sh.spec_slot[i] = P.spec_slot[i];
@@ -824,7 +880,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
       }
   }
   KG_SYNC();
-  if (sh.thr_lds) {
+  if (KG_UNI(sh.thr_lds)) {
     KG_FOR_THREADS(tid, NT) {
       for (int r = 0; r < P.R; ++r)
         for (uint32_t i = tid; i < sh.a_thr_n[r]; i += NT) sh.thr_val[sh.thr_base[r] + i] = P.thr_val[sh.a_thr_off[r] + i];
@@ -832,50 +888,49 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     KG_SYNC();
   }
   const uint32_t QCAP = S.qcap;
+  // ---- uniform state of the Solve
+  uint32_t qhead = 0, qlen = n_queue, epoch = 1;   // Queue ring; epoch/len implement lastLen
+  uint32_t nclaims = 0, seq = 0;                   // in-flight NodeClaims, placement steps
+  uint32_t ob = 0;                                 // current buffer of the scan order
+  bool ord_lds = true;                             // scan order still in LDS
+  uint32_t last_c = KG_NOIDX, last_npods = 0, last_stamp = 0, last_new = 0;  // the one claim touched since the reference's last sort
+  bool have_next = false, ctx_ready = false;       // next queue entry / its context already fetched
+  uint4 qe_next;
+  qe_next.x = qe_next.y = qe_next.z = qe_next.w = 0;
+  uint32_t passno = 0;
   while (true) {
     // ---- Queue.Pop
+    if (qlen == 0) break;
+    uint4 qe;
+    if (have_next) qe = qe_next; else qe = ((const KG_GLOBAL uint4*)S.queue)[qhead];
+    qe.x = KG_UNI(qe.x); qe.y = KG_UNI(qe.y); qe.z = KG_UNI(qe.z); qe.w = KG_UNI(qe.w);
+    if (qe.z == epoch && qe.w == qlen) break;  // every remaining pod failed with the queue at this length: done
+    const uint32_t pod = qe.x, variant = qe.y;
+    qhead = (qhead + 1) % QCAP;
+    qlen -= 1;
+    // ---- pod context: fetched during the previous placement, or now
+    if (!ctx_ready) {
+      KG_FOR_THREADS(tid, NT) { ctx_fetch<NT>(P, sh, tid, pod, variant); }
+      KG_SYNC();
+    }
     KG_FOR_THREADS(tid, NT) {
-      if (tid == 0) {
-        if (sh.qlen == 0) sh.done = 1;
-        else {
-          const uint4 qe = ((const KG_GLOBAL uint4*)S.queue)[sh.qhead % QCAP];
-          if (qe.z == sh.epoch && qe.w == sh.qlen) sh.done = 1;
-          else {
-            sh.pod = qe.x;
-            sh.qhead = (sh.qhead + 1) % QCAP;
-            sh.qlen -= 1;
-            sh.variant = qe.y;
-            sh.best = KG_NOIDX;
-            sh.reason = 0;
-          }
-        }
+      const uint64_t* src = (const uint64_t*)&sh.nx;
+      uint64_t* dst = (uint64_t*)&sh.pc;
+      for (uint32_t i = tid; i < sizeof(PodCtx) / 8; i += NT) dst[i] = src[i];
+      if (tid == NT - 1) {
+        sh.pod = pod; sh.variant = variant; sh.best = KG_NOIDX; sh.reason = 0;
+        uint32_t nd = 0;  // resources the pod requests
+        for (int r = 0; r < P.R; ++r) if (sh.nx.preq[r] != 0) nd |= 1u << r;
+        sh.need = nd;
       }
     }
+    // the entry behind the head is settled (a push lands behind it) when at least one pod is left
+    have_next = qlen >= 1;
+    if (have_next) qe_next = ((const KG_GLOBAL uint4*)S.queue)[qhead];  // (made uniform when it is popped)
+    bool want_pf = have_next;
+    ctx_ready = false;
     KG_SYNC();
-    if (sh.done) break;
-    // ---- pod context: one coalesced copy of the variant's precompiled record + its type mask + the pod's requests
-    KG_FOR_THREADS(tid, NT) {
-      const uint64_t* src = (const uint64_t*)(P.vctx + sh.variant);
-      uint64_t* dst = (uint64_t*)&sh.vc;
-      for (uint32_t i = tid; i < sizeof(VariantCtx) / 8; i += NT) dst[i] = src[i];
-      if (tid >= NT - KG_MAXR) {
-        const int r = tid - (NT - KG_MAXR);
-        sh.preq[r] = r < P.R ? P.preq[(size_t)sh.pod * P.R + r] : 0;
-      }
-      if (tid >= NT / 2 && tid < NT / 2 + KG_TWLDS && P.TW <= KG_TWLDS)  // zero-padded: the prefilter ANDs all KG_TWLDS words
-        sh.podmask[tid - NT / 2] = tid - NT / 2 < P.TW ? P.podmask[(size_t)sh.variant * P.TW + (tid - NT / 2)] : 0;
-      if (tid >= 96 && tid < 96 + KG_MAXE * KG_TWLDS && P.TW <= KG_TWLDS) {
-        // e_amask rows of the pod's requirement entries (entry ids straight from the global record: same round trip)
-        const uint32_t j = (uint32_t)(tid - 96) / KG_TWLDS, w = (uint32_t)(tid - 96) % KG_TWLDS;
-        const VariantCtx* gv = P.vctx + sh.variant;
-        if (j < gv->ne && w < (uint32_t)P.TW) sh.eam[j][w] = P.e_amask[(size_t)gv->ent[j].e * P.TW + w];
-      }
-      // (sh.placed & co are reset here, a barrier after the last uniform read of them, not in Queue.Pop)
-      // The reference sorts newNodeClaims at the start of the claim stage of every add(); what happens after (one pod
-      // added to a claim, or one claim appended) is not re-sorted, and Results returns the slice as it stands.
-      if (tid == 0) { sh.bestkey = ~0ull; sh.scan_base = 0; sh.placed = 0; sh.stage = 0; sh.tnext = 0; sh.result = 0; sh.winner = KG_NOIDX; }
-    }
-    KG_SYNC();
+    const uint32_t need = KG_UNI(sh.need);
     KG_T(0);
     // ---- existing nodes, first feasible in scan order
     for (uint32_t base = 0; base < (uint32_t)P.N; base += NT) {
@@ -885,137 +940,103 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
           uint32_t reason = 0;
           if (eval_node<false>(P, S, sh, n, &reason)) atomic_min_u32(&sh.best, n);
         }
+        if (want_pf) ctx_fetch<NT>(P, sh, tid, qe_next.x, qe_next.y);
       }
+      if (want_pf) { want_pf = false; ctx_ready = true; }
       KG_SYNC();
-      if (sh.best != KG_NOIDX) break;
+      if (KG_UNI(sh.best) != KG_NOIDX) break;
     }
-    if (sh.best != KG_NOIDX) {
+    if (KG_UNI(sh.best) != KG_NOIDX) {
       KG_FOR_THREADS(tid, NT) {
         if (tid == 0) {
           uint32_t reason = 0;
           eval_node<true>(P, S, sh, sh.best, &reason);
-          S.pod_kind[pod_row(S, sh.pod)] = 1;
-          S.pod_index[pod_row(S, sh.pod)] = (int32_t)sh.best;
+          S.pod_kind[pod_row(S, pod)] = 1;
+          S.pod_index[pod_row(S, pod)] = (int32_t)sh.best;
           if (STATS) S.counters[0] += sh.best + 1;
         }
       }
       KG_SYNC();
+      KG_T(1);
       continue;
     }
     if (STATS) {
-      KG_FOR_THREADS(tid, NT) { if (tid == 0) { S.counters[0] += P.N; sh.st_vis = 0; sh.st_types = 0; } }
+      KG_FOR_THREADS(tid, NT) { if (tid == 0) S.counters[0] += P.N; }
     }
     KG_T(1);
     // ---- in-flight NodeClaims (stage 0), then a new NodeClaim from each template in weight order (stage 1).
-    // Stage 0 finds the first feasible claim in (pod count, stable) order = minimum claim_key, in rounds of:
-    // prefilter a range of claims into the survivor list -> order the survivors -> exact NodeClaim.Add on them, GP at
-    // a time, until one accepts the pod; a later round only looks for keys below the best so far.  Stage 1 runs the
-    // same NodeClaim.Add on one freshly materialised claim per template.
-    KG_FOR_THREADS(tid, NT) { if (tid == 0) { sh.last_c = KG_NOIDX; sh.last_new = 0; } }
-    while (true) {
-      const uint32_t stage = sh.stage;
-      if (stage == 2) break;
+    // The claims are kept physically in the reference's scan order (pod count, then the stable order claim_key
+    // describes), so stage 0 walks the order in chunks of NT positions: a conservative prefilter (thread per position,
+    // ballot = survivors in order) -> exact NodeClaim.Add on the survivors, GP at a time, and the first claim that
+    // accepts the pod ends the scan.  Stage 1 runs the same NodeClaim.Add on one freshly materialised claim per template.
+    last_c = KG_NOIDX; last_new = 0;
+    uint32_t stage = 0, tnext = 0, base = 0, result = 0, win_g = 0;
+    while (stage != 2) {
       const bool fresh = stage == 1;
-      uint32_t ns = 0;
+      uint32_t nsv = 0;
       if (!fresh) {
-        KG_FOR_THREADS(tid, NT) { if (tid == 0) sh.nsurv = 0; }
-        KG_SYNC();
-        // prefilter: conservative, coalesced over claims.  With the visit counters on, every claim is evaluated exactly.
-        const uint32_t round_base = sh.scan_base;
-        uint32_t round_end = round_base;
-        for (; round_end < sh.nclaims && round_end + NT <= round_base + (uint32_t)KG_MAXSURV; round_end += NT) {
-          KG_FOR_THREADS(tid, NT) {
-            const uint32_t c = round_end + tid;
-            if (c < sh.nclaims) {
-              bool ok = true;
-              const uint32_t np_ = S.c_npods[c], st_ = S.c_stamp[c];
-              if (!STATS) {
-                // every load below is independent and UNCONDITIONAL (a load under a branch is not issued before the
-                // previous one has returned): one round trip to memory for the whole test
-                const uint32_t tm = S.c_tmpl[c];
-                int64_t hd[KG_MAXR];
+        if (base >= nclaims) { stage = (nclaims < (uint32_t)P.Cmax && P.NP > 0) ? 1 : 2; continue; }
+        const uint32_t chunk = nclaims - base < (uint32_t)NT ? nclaims - base : (uint32_t)NT;
+        KG_FOR_THREADS(tid, NT) {
+          bool ok = false;
+          KG_ST(0);
+          if ((uint32_t)tid < chunk) {
+            ok = true;
+            if (!STATS) {  // with the visit counters on, every claim is evaluated exactly
+              const uint32_t c = (uint32_t)ord_get(S, sh, P, ord_lds, ob, base + tid);
+              // every load below is independent, sits under scalar conditions only and is used after the last one has
+              // been issued: one round trip to memory for the whole test, and no more loads than the problem needs (the
+              // vector memory pipeline takes 16-34 cycles per 64-lane load: it, not latency, bounds this phase)
+              const uint32_t tm = S.c_tmpl[c];
+              int64_t hd[KG_MAXR];
 #pragma unroll
-                for (int r = 0; r < KG_MAXR; ++r) hd[r] = S.c_head[(size_t)(r < P.R ? r : 0) * P.Cmax + c];
-                uint64_t any = 0;
-                if (P.TW <= KG_TWLDS) {
-                  uint64_t mk[KG_TWLDS];
+              for (int r = 0; r < KG_MAXR; ++r) hd[r] = 0;
 #pragma unroll
-                  for (int w = 0; w < KG_TWLDS; ++w) mk[w] = S.c_mask[(size_t)(w < P.TW ? w : 0) * P.Cmax + c];
+              for (int r = 0; r < KG_MAXR; ++r) if ((need >> r) & 1) hd[r] = S.c_head[(size_t)r * P.Cmax + c];
+              uint64_t any = 0;
+              if (P.TW <= KG_TWLDS) {
+                uint64_t mk[KG_TWLDS];
 #pragma unroll
-                  for (int w = 0; w < KG_TWLDS; ++w) any |= mk[w] & sh.podmask[w];
-                } else {
-                  const uint64_t* pm = P.podmask + (size_t)sh.variant * P.TW;
-                  for (int w = 0; w < P.TW; ++w) any |= S.c_mask[(size_t)w * P.Cmax + c] & pm[w];
-                }
-                ok = ((P.tol_tmpl[sh.vc.v.tolset] >> tm) & 1) && sh.vc.v.host_claim_ok && any != 0;
+                for (int w = 0; w < KG_TWLDS; ++w) mk[w] = 0;
 #pragma unroll
-                for (int r = 0; r < KG_MAXR; ++r) ok = ok && (r >= P.R || sh.preq[r] == 0 || hd[r] >= sh.preq[r]);
+                for (int w = 0; w < KG_TWLDS; ++w) if (w < P.TW) mk[w] = S.c_mask[(size_t)w * P.Cmax + c];
+#pragma unroll
+                for (int w = 0; w < KG_TWLDS; ++w) any |= mk[w] & sh.pc.podmask[w];
+              } else {
+                const uint64_t* pm = P.podmask + (size_t)sh.variant * P.TW;
+                for (int w = 0; w < P.TW; ++w) any |= S.c_mask[(size_t)w * P.Cmax + c] & pm[w];
               }
-              if (ok) {
-                const unsigned long long key = claim_key(np_, st_, c);
-                if (key < sh.bestkey) {
-                  const uint32_t i = atomic_inc_u32(&sh.nsurv);
-                  sh.surv[i] = c;
-                  sh.skey[i] = key;
-                }
-              }
+              ok = ((P.tol_tmpl[sh.pc.vc.v.tolset] >> tm) & 1) && sh.pc.vc.v.host_claim_ok && any != 0;
+#pragma unroll
+              for (int r = 0; r < KG_MAXR; ++r) ok = ok && (!((need >> r) & 1) || hd[r] >= sh.pc.preq[r]);
             }
           }
-          KG_SYNC();
+          KG_ST(1);
+          wave_ballot_store(sh.ball, tid, ok);
+          if (want_pf) ctx_fetch<NT>(P, sh, tid, qe_next.x, qe_next.y);
+          KG_ST(2);
         }
+        if (want_pf) { want_pf = false; ctx_ready = true; }
+        KG_SYNC();
+        { KG_FOR_THREADS(tid, NT) { KG_ST(3); } }
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) nsv += (uint32_t)popc64(KG_UNI64(sh.ball[i]));
         KG_T(2);
-        // order the survivors by key (rank by counting; keys are unique)
-        ns = sh.nsurv;
-        // (PARTS threads share one survivor's count when the list is short)
-        uint32_t nsp = 1;
-        while (nsp < ns) nsp <<= 1;
-        const uint32_t PARTS = nsp >= (uint32_t)NT ? 1u : (uint32_t)NT / nsp;
-        if (PARTS > 1) {
-          KG_FOR_THREADS(tid, NT) { if ((uint32_t)tid < ns) sh.srank[tid] = 0; }
-          KG_SYNC();
-        }
-        KG_FOR_THREADS(tid, NT) {
-          if (PARTS > 1) {
-            const uint32_t i = (uint32_t)tid / PARTS, part = (uint32_t)tid % PARTS;
-            if (i < ns) {
-              const unsigned long long k = sh.skey[i];
-              const uint32_t per = (ns + PARTS - 1) / PARTS;
-              const uint32_t j0 = part * per, j1 = j0 + per < ns ? j0 + per : ns;
-              uint32_t r0 = 0;
-              for (uint32_t j = j0; j < j1; ++j) r0 += sh.skey[j] < k;
-              if (r0) atomic_add_u32(&sh.srank[i], r0);
-            }
-          } else {
-            for (uint32_t i = tid; i < ns; i += NT) {
-              const unsigned long long k = sh.skey[i];
-              uint32_t r0 = 0;
-              for (uint32_t j = 0; j < ns; ++j) r0 += sh.skey[j] < k;
-              sh.sorted[r0] = sh.surv[i];
-            }
-          }
-        }
-        if (PARTS > 1) {
-          KG_SYNC();
-          KG_FOR_THREADS(tid, NT) { if ((uint32_t)tid < ns) sh.sorted[sh.srank[tid]] = sh.surv[tid]; }
-        }
-        KG_FOR_THREADS(tid, NT) {
-          if (tid == 0) { sh.scan_base = round_end < sh.nclaims ? round_end : sh.nclaims; sh.pass_lo = 0; sh.winner = KG_NOIDX; }
-        }
-        KG_SYNC();
-        KG_T(3);
-        if (TIMERS) { KG_FOR_THREADS(tid, NT) { if (tid == 0) { S.counters[20] += ns; S.counters[21] += 1; } } }
+        if (TIMERS) { KG_FOR_THREADS(tid, NT) { if (tid == 0) { S.counters[20] += nsv; S.counters[21] += 1; } } }
       } else {
         // filterByRemainingResources + NewNodeClaim: materialise claim c = nclaims from template t into rows[0]
-        const uint32_t c = sh.nclaims;
-        const int t = (int)sh.tnext;
+        const uint32_t c = nclaims;
+        const int t = (int)tnext;
+        const uint32_t fl = tnext & 1;
         KG_FOR_THREADS(tid, NT) {
           Row& R = sh.rows[0];
           if (tid == 0) {
-            sh.fresh_lim = 0;
-            R.c = c; R.tmpl = (uint32_t)t; R.reason = 0; R.feas = 0; R.tv = 0; R.ent_changed = 0; R.ent_dne_ok = 0; R.sp_changed = 0; R.thr_use = 0;
-            R.ok = ((P.tol_tmpl[sh.vc.v.tolset] >> t) & 1) && sh.vc.v.host_claim_ok;
-            if (!R.ok) R.reason = ((P.tol_tmpl[sh.vc.v.tolset] >> t) & 1) ? 2u : 1u;
-            sh.sorted[0] = c; sh.pass_lo = 0; sh.winner = KG_NOIDX;
+            sh.fresh_lim[fl] = 0;
+            R.c = c; R.tmpl = (uint32_t)t; R.reason = 0; R.pos = nclaims; R.tv = 0; R.ent_changed = 0; R.ent_dne_ok = 0; R.sp_changed = 0; R.thr_use = 0;
+            R.npods = 0; R.stamp = 0;
+            R.ok = ((P.tol_tmpl[sh.pc.vc.v.tolset] >> t) & 1) && sh.pc.vc.v.host_claim_ok;
+            if (!R.ok) R.reason = ((P.tol_tmpl[sh.pc.vc.v.tolset] >> t) & 1) ? 2u : 1u;
+            sh.feas[passno & 1] = 0; sh.mvf[passno & 1] = 0;
           }
           for (int a = tid; a < P.Ka; a += NT) R.meta[a] = 0;
           for (int i = tid; i < P.Wa; i += NT) R.bits[i] = 0;
@@ -1037,7 +1058,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
               }
             }
             S.c_mask[(size_t)w * P.Cmax + c] = m;
-            if (m) sh.fresh_lim = 1;
+            if (m) sh.fresh_lim[fl] = 1;
           }
           // template requirement entries -> row
           const uint32_t rs = P.tmpl_rs[t];
@@ -1048,27 +1069,48 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
           }
         }
         KG_SYNC();
-        ns = sh.fresh_lim ? 1 : 0;
+        nsv = KG_UNI(sh.fresh_lim[fl]) ? 1 : 0;
+        KG_T(8);
       }
-      // ---- exact NodeClaim.Add in scan order: GP claims per pass, TWP threads each
-      while (sh.pass_lo < ns && sh.winner == KG_NOIDX) {
-        const uint32_t lo = sh.pass_lo;
+      // ---- exact NodeClaim.Add in scan order: up to GP claims per pass, TWP threads each
+      uint32_t lo = 0;
+      bool found = false;
+      while (lo < nsv && !found) {
+        // (the first survivor in order is the winner in most placements: a small first pass keeps the memory pipeline free)
+        const uint32_t gcap = (lo == 0 && !STATS && GP > (uint32_t)KG_GP0) ? (uint32_t)KG_GP0 : GP;
+        const uint32_t nrow = nsv - lo < gcap ? nsv - lo : gcap;
+        const uint32_t par = passno & 1;
+        passno += 1;
         if (!fresh) {
-          // load the claims' rows
+          // load the claims' rows: row gi <- the (lo + gi)-th survivor of the chunk
           KG_FOR_THREADS(tid, NT) {
             const uint32_t gi = (uint32_t)tid / TWP, w = (uint32_t)tid % TWP;
-            if (gi < GP && lo + gi < ns) {
+            if (tid == 0) { sh.feas[par] = 0; sh.mvf[par] = 0; }
+            if (gi < nrow) {
+              uint32_t rem = lo + gi, cpos = 0;
+              bool hit = false;
+#pragma unroll
+              for (int i = 0; i < NT / 64; ++i) {
+                const uint64_t b = KG_UNI64(sh.ball[i]);
+                const uint32_t pc = (uint32_t)popc64(b);
+                if (!hit && rem < pc) { cpos = (uint32_t)i * 64 + nth_set_bit(b, rem); hit = true; }
+                if (!hit) rem -= pc;
+              }
+              const uint32_t pos = base + cpos;
+              const unsigned long long oe = ord_get(S, sh, P, ord_lds, ob, pos);
+              const uint32_t c = (uint32_t)oe;
               Row& R = sh.rows[gi];
-              const uint32_t c = sh.sorted[lo + gi];
+              KG_ST(4);
               if (TWP == 16) {
-                // straight-line, independent loads (Ka <= 32 metas, Wa <= 64 words, R <= 8 requests): one round trip
-                // (unconditional loads from clamped rows, selected afterwards)
+                // straight-line, independent loads (Ka <= 32 metas, Wa <= 64 words, R <= 8 requests) from clamped
+                // rows, selected afterwards: one round trip
                 const uint32_t Ka1 = P.Ka > 0 ? (uint32_t)P.Ka - 1 : 0, Wa1 = P.Wa > 0 ? (uint32_t)P.Wa - 1 : 0, R1 = P.R > 0 ? (uint32_t)P.R - 1 : 0;
                 const uint32_t m0 = S.c_meta[(size_t)(w < Ka1 ? w : Ka1) * P.Cmax + c];
-                const uint32_t m1 = S.c_meta[(size_t)(w + 16 < Ka1 ? w + 16 : Ka1) * P.Cmax + c];
-                uint64_t b[4];
+                uint32_t m1 = 0;
+                if (P.Ka > 16) m1 = S.c_meta[(size_t)(w + 16 < Ka1 ? w + 16 : Ka1) * P.Cmax + c];
+                uint64_t b[4] = {0, 0, 0, 0};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) b[k] = S.c_bits[(size_t)(w + 16 * k < Wa1 ? w + 16 * k : Wa1) * P.Cmax + c];
+                for (int k = 0; k < 4; ++k) if (16 * k < P.Wa) b[k] = S.c_bits[(size_t)(w + 16 * k < Wa1 ? w + 16 * k : Wa1) * P.Cmax + c];
                 const int64_t rq = S.c_req[(size_t)(w < R1 ? w : R1) * P.Cmax + c];
                 R.meta[w] = w < (uint32_t)P.Ka ? m0 : 0; R.meta[w + 16] = w + 16 < (uint32_t)P.Ka ? m1 : 0;
 #pragma unroll
@@ -1081,172 +1123,174 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
               }
               if (w == TWP - 1) {
                 const uint32_t tm = S.c_tmpl[c];
-                R.npods = S.c_npods[c]; R.stamp = S.c_stamp[c];
-                R.c = c; R.tmpl = tm; R.reason = 0; R.feas = 0; R.tv = 0; R.ent_changed = 0; R.ent_dne_ok = 0; R.sp_changed = 0; R.thr_use = 0;
-                R.ok = ((P.tol_tmpl[sh.vc.v.tolset] >> tm) & 1) && sh.vc.v.host_claim_ok;
+                R.npods = (uint32_t)(oe >> 32); R.stamp = S.c_stamp[c];
+                R.c = c; R.tmpl = tm; R.reason = 0; R.pos = pos; R.tv = 0; R.ent_changed = 0; R.ent_dne_ok = 0; R.sp_changed = 0; R.thr_use = 0;
+                R.ok = ((P.tol_tmpl[sh.pc.vc.v.tolset] >> tm) & 1) && sh.pc.vc.v.host_claim_ok;
               }
             }
+            KG_ST(5);
           }
           KG_SYNC();
-          KG_T(8);
+          KG_T(3);
         }
-        // merge the pod: one thread per requirement entry, one per resource
+        // merge the pod: one thread per requirement entry (first half of the workgroup), one per resource (second
+        // half) -- the two kinds of work run in different waves instead of serialising inside one
         KG_FOR_THREADS(tid, NT) {
-          const uint32_t gi = (uint32_t)tid / TWP, w = (uint32_t)tid % TWP;
-          if (gi < GP && lo + gi < ns && sh.rows[gi].ok) {
-            if (w < sh.vc.ne) row_merge_entry(P, sh, sh.rows[gi], w, fresh);
-            else if (w >= 8 && w < 8 + (uint32_t)P.R) row_merge_resource(P, sh, sh.rows[gi], (int)w - 8, fresh);
+          if (tid == NT - 1) sh.endk = 0;
+          const uint32_t half = (uint32_t)tid / (NT / 2), t2 = (uint32_t)tid % (NT / 2);
+          const uint32_t gi = t2 / KG_MAXE, j = t2 % KG_MAXE;
+          if (gi < nrow && sh.rows[gi].ok) {
+            if (half == 0) { if (j < sh.pc.vc.ne) row_merge_entry(P, sh, sh.rows[gi], j, fresh); }
+            else if (j < (uint32_t)P.R) row_merge_resource(P, sh, sh.rows[gi], (int)j, fresh);
           }
+          KG_ST(6);
         }
         KG_SYNC();
-        if (sh.vc.nlist) {
+        if (KG_UNI(sh.pc.vc.nlist)) {
           KG_FOR_THREADS(tid, NT) {
             const uint32_t gi = (uint32_t)tid / TWP, w = (uint32_t)tid % TWP;
-            if (gi < GP && lo + gi < ns && w == 0 && sh.rows[gi].ok) row_topology(P, S, sh, sh.rows[gi]);
+            if (gi < nrow && w == 0 && sh.rows[gi].ok) row_topology(P, S, sh, sh.rows[gi]);
           }
           KG_SYNC();
         }
-        KG_T(9);
+        KG_T(4);
         // instance-type filter: one thread per 64-type word
         KG_FOR_THREADS(tid, NT) {
           const uint32_t gi = (uint32_t)tid / TWP, w = (uint32_t)tid % TWP;
-          if (gi < GP && lo + gi < ns && w < (uint32_t)P.TW && sh.rows[gi].ok) {
+          if (gi < nrow && w < (uint32_t)P.TW && sh.rows[gi].ok) {
             Row& R = sh.rows[gi];
             if (STATS) atomic_add_u32(&R.tv, (uint32_t)popc64(S.c_mask[(size_t)w * P.Cmax + R.c]));
             const uint64_t m = row_word(P, S, sh, R, fresh, (int)w);
             S.scratch[(size_t)w * P.Cmax + R.c] = m;
-            if (m) R.feas = 1;
+            if (m) atomic_or_u32(&sh.feas[par], 1u << gi);
           }
+          KG_ST(7);
         }
         KG_SYNC();
-        KG_T(10);
-        KG_FOR_THREADS(tid, NT) {
-          if (tid == 0) {
-            sh.need_refresh = 0;
-            for (uint32_t gi = 0; gi < GP && lo + gi < ns; ++gi) {
-              Row& R = sh.rows[gi];
-              bool ok = R.ok && R.feas;
-              if (ok && ((P.tmpl_minv_mask >> R.tmpl) & 1) && !claim_minvalues_ok(P, S, R.tmpl, R.c)) { ok = false; R.reason |= 32; }
-              if (R.ok && !ok) R.reason |= 8;
-              if (STATS) {
-                if (!fresh) S.scratch[(size_t)P.TW * P.Cmax + R.c] = R.ok ? R.tv : 0;
-                else { S.counters[3] += 1; if (R.ok) S.counters[2] += R.tv; }
-              }
-              if (ok) { sh.winner = R.c; sh.win_g = gi; break; }
-              if (TIMERS) S.counters[22] += 1;
-              // the prefilter let an infeasible claim through: recompute its headroom if its options changed since
-              if (!fresh && !STATS && S.c_hstamp[R.c] != S.c_stamp[R.c]) { R.feas = 2; S.c_hstamp[R.c] = S.c_stamp[R.c]; sh.need_refresh = 1; }
-            }
-            sh.pass_lo = lo + GP;
-            if (TIMERS) S.counters[23] += 1;
-          }
-        }
-        KG_SYNC();
-        KG_T(11);
-        if (sh.need_refresh) {
-          // tighten the headroom of false survivors
+        if (P.tmpl_minv_mask != 0) {
+          // InstanceTypes.SatisfiesMinValues on the candidate option masks
           KG_FOR_THREADS(tid, NT) {
-            const uint32_t gi = (uint32_t)tid / KG_MAXR;
-            const int r = tid % KG_MAXR;
-            if (gi < GP && lo + gi < ns && r < P.R && sh.rows[gi].feas == 2) claim_refresh_head(P, S, sh, sh.rows[gi].c, r);
+            const uint32_t gi = (uint32_t)tid / TWP, w = (uint32_t)tid % TWP;
+            if (gi < nrow && w == 0 && ((sh.feas[par] >> gi) & 1)) {
+              const Row& R = sh.rows[gi];
+              if (((P.tmpl_minv_mask >> R.tmpl) & 1) && !claim_minvalues_ok(P, S, R.tmpl, R.c)) atomic_or_u32(&sh.mvf[par], 1u << gi);
+            }
           }
           KG_SYNC();
         }
-      }
-      KG_T(4);
-      // ---- verdict of this round / attempt
-      const bool more_rounds = !fresh && sh.scan_base < sh.nclaims;
-      if (more_rounds && sh.winner != KG_NOIDX) {
-        // keep the winner's merged row: later rounds reuse the evaluation groups
+        KG_T(5);
+        // ---- the first row in order whose option mask stays non-empty takes the pod (every thread reads the same words)
+        const uint32_t fm = KG_UNI(sh.feas[par] & ~sh.mvf[par]);
+        found = fm != 0;
+        win_g = found ? (uint32_t)ctz64((uint64_t)fm) : 0;
+        const uint32_t nlose = found ? win_g : nrow;  // rows evaluated and refused before the winner
         KG_FOR_THREADS(tid, NT) {
-          const uint64_t* src = (const uint64_t*)&sh.rows[sh.win_g];
-          uint64_t* dst = (uint64_t*)&sh.wrow;
-          for (uint32_t i = tid; i < sizeof(Row) / 8; i += NT) dst[i] = src[i];
+          const uint32_t gi = (uint32_t)tid / TWP, w = (uint32_t)tid % TWP;
+          if (!fresh && !STATS && gi < nlose) {
+            // the prefilter let an infeasible claim through: recompute its headroom if its options changed since
+            const uint32_t c = sh.rows[gi].c;
+            const uint32_t st = S.c_stamp[c];
+            if (S.c_hstamp[c] != st) {
+              if (w < (uint32_t)P.R) claim_refresh_head(P, S, sh, c, (int)w);
+              if (w == TWP - 1) S.c_hstamp[c] = st;  // (the group's last thread: after every thread of the group has compared)
+            }
+          }
+          if (found) {
+            // end of the pod-count group the claim belongs to after this pod's arrival is decided by where the group it
+            // leaves ends: positions are sorted by pod count
+            const uint32_t k = fresh ? 1u : KG_UNI(sh.rows[win_g].npods);
+            for (uint32_t p = tid; p < nclaims; p += NT) {
+              const uint32_t np = (uint32_t)(ord_get(S, sh, P, ord_lds, ob, p) >> 32);
+              const uint32_t nn = p + 1 < nclaims ? (uint32_t)(ord_get(S, sh, P, ord_lds, ob, p + 1) >> 32) : 0xFFFFFFFFu;
+              if (np <= k && nn > k) sh.endk = p + 1;
+            }
+          }
+          if (tid == 0) {
+            if (fresh && !found) {
+              const Row& R = sh.rows[0];
+              uint32_t rr = R.reason;
+              if (R.ok) rr |= ((sh.mvf[par] & 1) ? 32u : 0u) | 8u;
+              sh.reason |= rr;
+            }
+            if (STATS) {
+              // rows the reference visits: every claim up to and including the first feasible one; a visited claim's
+              // options count when the pod got as far as the instance-type filter
+              const uint32_t nvis = found ? win_g + 1 : nrow;
+              for (uint32_t g2 = 0; g2 < nvis; ++g2) {
+                const Row& R = sh.rows[g2];
+                if (!fresh) S.counters[1] += 1; else S.counters[3] += 1;
+                if (R.ok) S.counters[2] += R.tv;
+              }
+            }
+            if (TIMERS) { S.counters[22] += fresh ? 0 : nlose; S.counters[23] += 1; }
+          }
+          KG_ST(8);
         }
         KG_SYNC();
+        KG_T(6);
+        lo += nrow;
       }
-      KG_FOR_THREADS(tid, NT) {
-        if (tid == 0) {
-          if (!fresh) {
-            if (sh.winner != KG_NOIDX) {
-              const Row& W = sh.rows[sh.win_g];
-              sh.bestkey = claim_key(W.npods, W.stamp, W.c);
-              sh.result = more_rounds ? 3 : 1;  // 3: the row was parked in wrow
-            }
-            if (!more_rounds) sh.stage = sh.bestkey != ~0ull ? 2 : ((sh.nclaims < (uint32_t)P.Cmax && P.NP > 0) ? 1 : 2);
-          } else {
-            if (sh.winner != KG_NOIDX) { sh.result = 2; sh.stage = 2; }
-            else {
-              sh.reason |= ns ? sh.rows[0].reason : 16u;  // 16: all available instance types exceed limits
-              sh.tnext += 1;
-              if (sh.tnext >= (uint32_t)P.NP) sh.stage = 2;
-            }
-          }
+      // ---- verdict of this chunk / attempt
+      if (!fresh) {
+        if (found) { result = 1; stage = 2; }
+        else base += NT;
+      } else {
+        if (found) { result = 2; stage = 2; }
+        else {
+          if (nsv == 0) { KG_FOR_THREADS(tid, NT) { if (tid == 0) sh.reason |= 16u; } }  // all available instance types exceed limits
+          tnext += 1;
+          if (tnext >= (uint32_t)P.NP) stage = 2;
         }
       }
-      KG_SYNC();
     }
-    if (STATS) {
-      // rows the reference visits: every claim up to and including the first feasible one; a visited claim's options
-      // count when the pod got as far as the instance-type filter (recorded in scratch row TW by the exact pass)
-      for (uint32_t base = 0; base < sh.nclaims; base += NT) {
-        KG_FOR_THREADS(tid, NT) {
-          const uint32_t c = base + tid;
-          if (c < sh.nclaims && sh.result != 2 && claim_key(S.c_npods[c], S.c_stamp[c], c) <= sh.bestkey) {
-            atomic_add_u32(&sh.st_vis, 1u);
-            atomic_add_u64(&sh.st_types, S.scratch[(size_t)P.TW * P.Cmax + c]);
-          }
-          // a pod that ends on a fresh claim (or nowhere) visited every in-flight claim
-          if (c < sh.nclaims && sh.result == 2) {
-            atomic_add_u32(&sh.st_vis, 1u);
-            atomic_add_u64(&sh.st_types, S.scratch[(size_t)P.TW * P.Cmax + c]);
-          }
-        }
-      }
-      KG_SYNC();
+    if (result != 0) {
+      // ---- commit NodeClaim.Add: the merged row goes back to the claim, the option mask comes from scratch, the claim
+      // moves to the front of the next pod-count group of the scan order (a new claim: to the end of the one-pod group)
+      const bool fr = result == 2;
+      const uint32_t nnew = nclaims + (fr ? 1u : 0u);
+      const bool dst_lds = ord_lds && nnew <= (uint32_t)KG_ORD;
+      const uint32_t wc = KG_UNI(sh.rows[win_g].c), wpos = KG_UNI(sh.rows[win_g].pos), wnp = KG_UNI(sh.rows[win_g].npods), wst = KG_UNI(sh.rows[win_g].stamp);
+      const uint32_t endk = KG_UNI(sh.endk);
       KG_FOR_THREADS(tid, NT) {
-        if (tid == 0) { S.counters[1] += sh.st_vis; S.counters[2] += sh.st_types; }
-      }
-    }
-    KG_T(5);
-    if (sh.result != 0) {
-      // ---- commit NodeClaim.Add: the merged row goes back to the claim, the option mask comes from scratch
-      const bool fresh = sh.result == 2;
-      KG_FOR_THREADS(tid, NT) {
-        const Row& R = sh.result == 3 ? sh.wrow : sh.rows[sh.win_g];
-        const uint32_t c = R.c;
-        for (int a = tid; a < P.Ka; a += NT) S.c_meta[(size_t)a * P.Cmax + c] = R.meta[a];
-        for (int i = tid; i < P.Wa; i += NT) S.c_bits[(size_t)i * P.Cmax + c] = R.bits[i];
-        for (int w = tid; w < P.TW; w += NT) S.c_mask[(size_t)w * P.Cmax + c] = S.scratch[(size_t)w * P.Cmax + c];
+        const Row& R = sh.rows[win_g];
+        const uint32_t c = wc;
+        // (each small task starts in a different wave: no wave runs all of them one after the other)
+        for (int a = (tid + NT - 64) % NT; a < P.Ka; a += NT) S.c_meta[(size_t)a * P.Cmax + c] = R.meta[a];
+        for (int i = (tid + NT - 128) % NT; i < P.Wa; i += NT) S.c_bits[(size_t)i * P.Cmax + c] = R.bits[i];
+        for (int w = (tid + NT - 192) % NT; w < P.TW; w += NT) S.c_mask[(size_t)w * P.Cmax + c] = S.scratch[(size_t)w * P.Cmax + c];
         if (tid >= NT - KG_MAXR) {
           const int r = tid - (NT - KG_MAXR);
           if (r < P.R) {
             S.c_req[(size_t)r * P.Cmax + c] = R.req[r];
-            if (!fresh && sh.preq[r] != 0) S.c_head[(size_t)r * P.Cmax + c] -= sh.preq[r];
+            if (!fr && sh.pc.preq[r] != 0) S.c_head[(size_t)r * P.Cmax + c] -= sh.pc.preq[r];
           }
         }
         if (tid == NT / 2) {
-          if (fresh) {
-            S.c_npods[c] = 1; S.c_tmpl[c] = (uint16_t)R.tmpl;
-            sh.last_c = c; sh.last_new = 1;
-            sh.nclaims += 1;
-          } else {
-            sh.last_c = c; sh.last_npods = R.npods; sh.last_stamp = R.stamp; sh.last_new = 0;
-            S.c_npods[c] = R.npods + 1;
-          }
-          S.c_stamp[c] = ++sh.seq;
-          if (fresh) S.c_hstamp[c] = sh.seq;
-          S.pod_kind[pod_row(S, sh.pod)] = 2;
-          S.pod_index[pod_row(S, sh.pod)] = (int32_t)c;
+          if (fr) { S.c_npods[c] = 1; S.c_tmpl[c] = (uint16_t)R.tmpl; S.c_hstamp[c] = seq + 1; }
+          else S.c_npods[c] = wnp + 1;
+          S.c_stamp[c] = seq + 1;
+          S.pod_kind[pod_row(S, pod)] = 2;
+          S.pod_index[pod_row(S, pod)] = (int32_t)c;
           row_record_topology(P, S, sh, R);
         }
+        // scan order -> the other buffer
+        for (uint32_t p = tid; p < nclaims; p += NT) {
+          unsigned long long v = ord_get(S, sh, P, ord_lds, ob, p);
+          uint32_t q = p;
+          if (fr) q = p < endk ? p : p + 1;
+          else if (p == wpos) { q = endk - 1; v = ((unsigned long long)(wnp + 1) << 32) | c; }
+          else if (p > wpos && p < endk) q = p - 1;
+          ord_set(S, sh, P, dst_lds, ob ^ 1, q, v);
+        }
+        if (fr && tid == NT - 1) ord_set(S, sh, P, dst_lds, ob ^ 1, endk, (1ull << 32) | c);
+        KG_ST(9);
       }
       KG_SYNC();
-      if (fresh) {
+      if (fr) {
         KG_FOR_THREADS(tid, NT) {
           // headroom of the new claim; subtractMax: charge the worst-case capacity of the remaining options against the limits
-          const uint32_t c = sh.rows[sh.win_g].c;
-          const int t = (int)sh.rows[sh.win_g].tmpl;
+          const uint32_t c = wc;
+          const int t = (int)KG_UNI(sh.rows[win_g].tmpl);
           if (tid < P.R) claim_refresh_head(P, S, sh, c, tid);
           if (tid >= 64 && tid < 64 + P.R && P.tmpl_has_limits[t]) {
             const int r = tid - 64;
@@ -1264,42 +1308,48 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
         }
         KG_SYNC();
       }
-      KG_T(6);
+      last_c = wc; last_new = fr ? 1u : 0u;
+      if (!fr) { last_npods = wnp; last_stamp = wst; }
+      ob ^= 1; ord_lds = dst_lds; nclaims = nnew; seq += 1;
+      KG_T(7);
       continue;
     }
     // ---- Preferences.Relax + Queue.Push
+    const int32_t vnext = (int32_t)KG_UNI((uint32_t)sh.pc.vc.v.next);
     KG_FOR_THREADS(tid, NT) {
       if (tid == 0) {
-        const uint32_t pod = sh.pod;
         S.pod_kind[pod_row(S, pod)] = 0;
         S.pod_index[pod_row(S, pod)] = -1;
         S.pod_reason[pod_row(S, pod)] = sh.reason ? sh.reason : 8;
-        uint4 qe;
-        qe.x = pod;
-        sh.qlen += 1;
-        if (sh.vc.v.next >= 0) {
-          qe.y = (uint32_t)sh.vc.v.next;
-          qe.z = 0; qe.w = 0;
-          sh.epoch += 1;  // lastLen = {} on a relaxed push
+        uint4 qn;
+        qn.x = pod;
+        if (vnext >= 0) {
+          qn.y = (uint32_t)vnext;
+          qn.z = 0; qn.w = 0;
           S.header[1] += 1;
         } else {
-          qe.y = sh.variant;
-          qe.z = sh.epoch; qe.w = sh.qlen;  // lastLen[pod] = len(queue) after the push
+          qn.y = variant;
+          qn.z = epoch; qn.w = qlen + 1;  // lastLen[pod] = len(queue) after the push
         }
-        ((KG_GLOBAL uint4*)S.queue)[(sh.qhead + sh.qlen - 1) % QCAP] = qe;
+        ((KG_GLOBAL uint4*)S.queue)[(qhead + qlen) % QCAP] = qn;
       }
     }
+    qlen += 1;
+    if (vnext >= 0) epoch += 1;  // lastLen = {} on a relaxed push
+    // the pushed entry is the head when nothing else is queued: it was not there when the next entry was fetched
+    if (qlen == 1) { have_next = false; ctx_ready = false; }
     KG_SYNC();
-    KG_T(7);
+    KG_T(9);
   }
   KG_FOR_THREADS(tid, NT) {
     if (tid == 0) {
-      S.header[0] = sh.nclaims;
-      S.header[2] = sh.last_c; S.header[3] = sh.last_npods; S.header[4] = sh.last_stamp; S.header[5] = sh.last_new;
+      S.header[0] = nclaims;
+      S.header[2] = last_c; S.header[3] = last_npods; S.header[4] = last_stamp; S.header[5] = last_new;
     }
   }
   KG_SYNC();
 #undef KG_T
+#undef KG_ST
 }
 
 }  // namespace kg

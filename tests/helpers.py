@@ -96,4 +96,13 @@ def scenario(name):
         n_nodes, n_pods = (100, 1500) if name == "c5_small" else (600, 12000)
         nodes, bound = wl.existing_cluster(n_nodes, 13, t6, z6, nodepool="np-a")
         return Problem(t6, wl.mixed_pods(n_pods, 99, z6, families(t6)), c5_nodepools(), nodes=nodes, bound=bound)
+    if name == "many_claims":
+        # more NodeClaims in flight than the scan order the kernel keeps in LDS (KG_ORD = 2048): 2200 pods with hostname
+        # self-anti-affinity (one per node), then small pods that land on those claims and reorder them
+        sel = {"match_labels": {"app": "solo"}}
+        big = [{"uid": "solo-%05d" % i, "ns": "default", "creation_ts": 1700000000, "labels": {"app": "solo"},
+                "requests": {"cpu": 2000, "memory": 4 * wl.GI * 1000},
+                "anti_affinity_required": [{"key": wl.L_HOSTNAME, "selector": sel}]} for i in range(2200)]
+        small = wl.mixed_pods(500, 8, zones, families(types), prefix="small")
+        return Problem(types, big + small, [wl.default_nodepool()])
     raise KeyError(name)

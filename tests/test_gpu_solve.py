@@ -71,6 +71,34 @@ def test_scenarios(L, name):
     check(L, scenario(name))
 
 
+@pytest.mark.parametrize("name", ["c3_small", "c3_mid", "c3_large", "existing_small", "existing_mid", "existing_large", "c5_small", "c5_mid"])
+def test_scenarios_prefilter_path(L, name):
+    """The same scenarios with the visit counters off (the production setting): prefilter + small first pass."""
+    prob = scenario(name)
+    ro = prob.run_oracle()
+    L.set_collect_stats(False)
+    try:
+        rg = prob.run_library(L)
+    finally:
+        L.set_collect_stats(True)
+    d = diff_results(ro.decode(), rg.decode())
+    assert d == "", d
+
+
+def test_more_claims_than_the_lds_scan_order(L):
+    """> 2048 NodeClaims in flight: the scan order moves from LDS to global memory mid-solve; both counter settings."""
+    prob = scenario("many_claims")
+    ro, rg = check(L, prob)
+    assert rg.res.n_claims > 2048
+    L.set_collect_stats(False)
+    try:
+        rg2 = prob.run_library(L)
+    finally:
+        L.set_collect_stats(True)
+    d = diff_results(ro.decode(), rg2.decode())
+    assert d == "", d
+
+
 def test_launch_filter_and_truncate(L):
     from tests.launch_common import check_launch, check_reference_pins
     check_launch(L)

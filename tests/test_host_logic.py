@@ -75,6 +75,36 @@ def test_scenarios(L, name):
         assert any(k == 1 for k, _ in ro.decode()["pods"])
 
 
+@pytest.mark.parametrize("name", ["c3_small", "c3_mid", "existing_small", "c5_small"])
+def test_scenarios_prefilter_path(L, name):
+    """The same scenarios with the visit counters off (the production setting): prefilter + small first pass."""
+    from tests.helpers import scenario
+    prob = scenario(name)
+    ro = prob.run_oracle()
+    L.set_collect_stats(False)
+    try:
+        rg = prob.run_library(L)
+    finally:
+        L.set_collect_stats(True)
+    d = diff_results(ro.decode(), rg.decode())
+    assert d == "", d
+
+
+def test_more_claims_than_the_lds_scan_order(L):
+    """> 2048 NodeClaims in flight: the scan order moves from LDS to global memory mid-solve; both counter settings."""
+    from tests.helpers import scenario
+    prob = scenario("many_claims")
+    ro, rg = check(L, prob)
+    assert rg.res.n_claims > 2048
+    L.set_collect_stats(False)
+    try:
+        rg2 = prob.run_library(L)
+    finally:
+        L.set_collect_stats(True)
+    d = diff_results(ro.decode(), rg2.decode())
+    assert d == "", d
+
+
 def test_launch_filter_and_truncate(L):
     from tests.launch_common import check_launch, check_reference_pins
     check_launch(L)
