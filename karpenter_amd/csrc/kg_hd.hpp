@@ -30,9 +30,12 @@ inline void atomic_or_u32(uint32_t* p, uint32_t v) { *p |= v; }
 inline void atomic_add_u64(unsigned long long* p, unsigned long long v) { *p += v; }
 inline unsigned long long now_ticks() { return 0; }
 // word `tid / 64` of slots <- the predicate of the 64 threads tid belongs to (the emulation runs them in ascending order)
-inline void wave_ballot_store(unsigned long long* slots, int tid, bool pred) {
+// returns the number of lower-numbered threads of the same 64 whose predicate holds
+inline uint32_t wave_ballot_store(unsigned long long* slots, int tid, bool pred) {
   if ((tid & 63) == 0) slots[tid >> 6] = 0;
+  const uint32_t rank = (uint32_t)__builtin_popcountll(slots[tid >> 6]);
   if (pred) slots[tid >> 6] |= 1ull << (tid & 63);
+  return rank;
 }
 inline int popc64(uint64_t x) { return __builtin_popcountll(x); }
 inline int ctz64(uint64_t x) { return __builtin_ctzll(x); }
@@ -71,9 +74,11 @@ __device__ __forceinline__ void atomic_or_u32(uint32_t* p, uint32_t v) { atomicO
 __device__ __forceinline__ void atomic_add_u64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
 __device__ __forceinline__ unsigned long long now_ticks() { return wall_clock64(); }  // 100 MHz
 // word `tid / 64` of slots <- the wave's ballot (every thread of the workgroup must call it)
-__device__ __forceinline__ void wave_ballot_store(unsigned long long* slots, int tid, bool pred) {
+// returns the number of lower lanes whose predicate holds
+__device__ __forceinline__ uint32_t wave_ballot_store(unsigned long long* slots, int tid, bool pred) {
   const unsigned long long b = __ballot(pred);
   if ((tid & 63) == 0) slots[tid >> 6] = b;
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
 }
 __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
 __device__ __forceinline__ int ctz64(uint64_t x) { return __ffsll((unsigned long long)x) - 1; }

@@ -224,6 +224,7 @@ struct Row {
   int32_t thr_idx[KG_MAXR];
   int64_t req[KG_MAXR];            // claim requests; after the merge: requests including the pod
   uint64_t topo[KG_MAXSPEC];       // Topology.AddRequirements result per special key
+  uint64_t mw[2][KG_TWLDS];        // the two halves of the type filter when two waves share a claim
   uint32_t meta[KG_MAXKA];         // requirement meta per active key
   uint64_t bits[KG_ROWW];          // requirement value bits, Wa words
 };
@@ -245,6 +246,7 @@ struct Shared {
   uint32_t feas[2], mvf[2];         // per pass (alternating): rows whose option mask stays non-empty / rows failing minValues
   uint32_t endk, need;              // end of the winner's pod-count group in the scan order; resources the pod requests
   unsigned long long ball[16];      // prefilter ballots of the current chunk of scan positions, one word per wave
+  uint16_t wpos[16][KG_MAXGP];      // chunk positions of each wave's first survivors, in order
   PodCtx pc;                        // the pod being placed
   PodCtx nx;                        // the next pod of the queue, fetched while the current one is placed
   uint64_t offm[KG_OFFROWS][KG_TWLDS];          // offering masks [zone * n_ct + ct]
@@ -540,7 +542,10 @@ KG_HD void row_topology(const DevProblem& P, const SimState& S, const Shared& sh
 }
 
 // Step 6: filterInstanceTypesByRequirements in type-mask space: word w of the claim's remaining options after the pod.
-KG_HD uint64_t row_word(const DevProblem& P, const SimState& S, const Shared& sh, const Row& R, bool fresh, int w) {
+// The filter is an AND of independent terms; it is cut in two halves of similar length so that two waves can each
+// run one of them for the same claim (a wave issues one instruction per ~4 cycles: the stream's length is the cost).
+// Half A: the claim's current options, the pod's entries on ordinary keys, the template's entries (fresh claim), fits.
+KG_HD uint64_t row_word_a(const DevProblem& P, const SimState& S, const Shared& sh, const Row& R, bool fresh, int w) {
   uint64_t m = S.c_mask[(size_t)w * P.Cmax + R.c];
   const uint32_t ne = sh.pc.vc.ne;
   // pod entries on ordinary keys
@@ -573,7 +578,26 @@ KG_HD uint64_t row_word(const DevProblem& P, const SimState& S, const Shared& sh
       m &= f;
     }
   }
-  // special keys: types whose value set meets the merged allowed set; offering selection from zone / capacity type
+  // fits
+  {
+    uint64_t tm[KG_MAXR];
+#pragma unroll
+    for (int r = 0; r < KG_MAXR; ++r) {
+      const bool use = r < P.R && ((R.thr_use >> r) & 1);
+      const bool none = use && R.thr_idx[r] >= (int)sh.a_thr_n[r];
+      uint64_t v = 0;
+      if (r < P.R) v = P.thr_mask[((size_t)sh.a_thr_off[r] + ((use && !none) ? R.thr_idx[r] : 0)) * P.TW + w];  // under a scalar condition only
+      tm[r] = !use ? ~0ull : (none ? 0ull : v);
+    }
+#pragma unroll
+    for (int r = 0; r < KG_MAXR; ++r) m &= tm[r];
+  }
+  if (fresh) m &= P.valid_types[w];
+  return m;
+}
+// Half B: the special keys (types whose value set meets the merged allowed set) and hasOffering from zone / capacity type.
+KG_HD uint64_t row_word_b(const DevProblem& P, const SimState& S, const Shared& sh, const Row& R, bool fresh, int w) {
+  uint64_t m = ~0ull;
   bool off_use = fresh;
   uint64_t zmask = ~0ull, ctmask = ~0ull;
   for (int i = 0; i < P.nspec; ++i) {
@@ -608,21 +632,6 @@ KG_HD uint64_t row_word(const DevProblem& P, const SimState& S, const Shared& sh
       zmask &= zm;
     }
   }
-  // fits
-  {
-    uint64_t tm[KG_MAXR];
-#pragma unroll
-    for (int r = 0; r < KG_MAXR; ++r) {
-      const bool use = r < P.R && ((R.thr_use >> r) & 1);
-      const bool none = use && R.thr_idx[r] >= (int)sh.a_thr_n[r];
-      uint64_t v = 0;
-      if (r < P.R) v = P.thr_mask[((size_t)sh.a_thr_off[r] + ((use && !none) ? R.thr_idx[r] : 0)) * P.TW + w];  // under a scalar condition only
-      tm[r] = !use ? ~0ull : (none ? 0ull : v);
-    }
-#pragma unroll
-    for (int r = 0; r < KG_MAXR; ++r) m &= tm[r];
-  }
-  if (fresh) m &= P.valid_types[w];
   // hasOffering
   if (off_use) {
     uint64_t f = 0;
@@ -1012,7 +1021,8 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
             }
           }
           KG_ST(1);
-          wave_ballot_store(sh.ball, tid, ok);
+          const uint32_t rank = wave_ballot_store(sh.ball, tid, ok);
+          if (ok && rank < (uint32_t)KG_MAXGP) sh.wpos[tid >> 6][rank] = (uint16_t)tid;
           if (want_pf) ctx_fetch<NT>(P, sh, tid, qe_next.x, qe_next.y);
           KG_ST(2);
         }
@@ -1087,15 +1097,16 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
             const uint32_t gi = (uint32_t)tid / TWP, w = (uint32_t)tid % TWP;
             if (tid == 0) { sh.feas[par] = 0; sh.mvf[par] = 0; }
             if (gi < nrow) {
-              uint32_t rem = lo + gi, cpos = 0;
+              // the (lo + gi)-th survivor: which wave's ballot holds it, and its rank there
+              uint32_t rem = lo + gi, wv = 0;
               bool hit = false;
 #pragma unroll
               for (int i = 0; i < NT / 64; ++i) {
-                const uint64_t b = KG_UNI64(sh.ball[i]);
-                const uint32_t pc = (uint32_t)popc64(b);
-                if (!hit && rem < pc) { cpos = (uint32_t)i * 64 + nth_set_bit(b, rem); hit = true; }
+                const uint32_t pc = (uint32_t)popc64(KG_UNI64(sh.ball[i]));
+                if (!hit && rem < pc) { wv = (uint32_t)i; hit = true; }
                 if (!hit) rem -= pc;
               }
+              const uint32_t cpos = rem < (uint32_t)KG_MAXGP ? (uint32_t)sh.wpos[wv][rem] : wv * 64 + nth_set_bit(sh.ball[wv], rem);
               const uint32_t pos = base + cpos;
               const unsigned long long oe = ord_get(S, sh, P, ord_lds, ob, pos);
               const uint32_t c = (uint32_t)oe;
@@ -1154,19 +1165,38 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
           KG_SYNC();
         }
         KG_T(4);
-        // instance-type filter: one thread per 64-type word
+        // instance-type filter: one thread per 64-type word; when the pass is small enough, two threads (in
+        // different waves) per word, one for each half of the filter
+        const bool split = nrow * TWP * 2 <= (uint32_t)NT && P.TW <= KG_TWLDS;
         KG_FOR_THREADS(tid, NT) {
-          const uint32_t gi = (uint32_t)tid / TWP, w = (uint32_t)tid % TWP;
+          const uint32_t half = split ? (uint32_t)tid / (NT / 2) : 0, t2 = split ? (uint32_t)tid % (NT / 2) : (uint32_t)tid;
+          const uint32_t gi = t2 / TWP, w = t2 % TWP;
           if (gi < nrow && w < (uint32_t)P.TW && sh.rows[gi].ok) {
             Row& R = sh.rows[gi];
-            if (STATS) atomic_add_u32(&R.tv, (uint32_t)popc64(S.c_mask[(size_t)w * P.Cmax + R.c]));
-            const uint64_t m = row_word(P, S, sh, R, fresh, (int)w);
-            S.scratch[(size_t)w * P.Cmax + R.c] = m;
-            if (m) atomic_or_u32(&sh.feas[par], 1u << gi);
+            if (STATS && half == 0) atomic_add_u32(&R.tv, (uint32_t)popc64(S.c_mask[(size_t)w * P.Cmax + R.c]));
+            if (split) {
+              R.mw[half][w] = half == 0 ? row_word_a(P, S, sh, R, fresh, (int)w) : row_word_b(P, S, sh, R, fresh, (int)w);
+            } else {
+              const uint64_t m = row_word_a(P, S, sh, R, fresh, (int)w) & row_word_b(P, S, sh, R, fresh, (int)w);
+              S.scratch[(size_t)w * P.Cmax + R.c] = m;
+              if (m) atomic_or_u32(&sh.feas[par], 1u << gi);
+            }
           }
           KG_ST(7);
         }
         KG_SYNC();
+        if (split) {
+          KG_FOR_THREADS(tid, NT) {
+            const uint32_t gi = (uint32_t)tid / TWP, w = (uint32_t)tid % TWP;
+            if (gi < nrow && w < (uint32_t)P.TW && sh.rows[gi].ok) {
+              const Row& R = sh.rows[gi];
+              const uint64_t m = R.mw[0][w] & R.mw[1][w];
+              S.scratch[(size_t)w * P.Cmax + R.c] = m;
+              if (m) atomic_or_u32(&sh.feas[par], 1u << gi);
+            }
+          }
+          KG_SYNC();
+        }
         if (P.tmpl_minv_mask != 0) {
           // InstanceTypes.SatisfiesMinValues on the candidate option masks
           KG_FOR_THREADS(tid, NT) {
