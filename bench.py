@@ -31,6 +31,17 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
+def pmc_traffic(n_pods):
+    """HBM bytes per k_solve launch on this workload, from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE, each
+    its own run; gfx950 correction of MI355X_MICROARCH.md applied) -- counters cannot be read from inside the run.  None
+    for any workload other than the one profiled."""
+    path = os.path.join(ROOT, "profiles", "r01d_k_solve_pmc.json")
+    if n_pods != 10000 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get("k_solve_traffic_bytes")
+
+
 def bench_consolidation(args, L, hcat, types, zones, world, rank, barrier, dist, torch):
     """C4: consolidation on a synthetic cluster (seed 11), single- and multi-node, units sharded over the ranks."""
     from karpenter_amd import abi, distributed, workloads as wl
@@ -152,7 +163,7 @@ def main():
             "breakdown_ms": {"host_compile": sum(compile_ms) / len(compile_ms), "prepass_kernels": sum(pre_ms) / len(pre_ms),
                              "k_solve": k_ms, "host_decode_truncate": sum(decode_ms) / len(decode_ms)},
             "roofline": {"bound": "hbm", "kernel": "k_solve", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.pods),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "rows the reference algorithm visits up to its first feasible index (SURVEY.md 8d): "
                                  "212 B/existing node, 400 B/NodeClaim, 336 B/instance type"},
