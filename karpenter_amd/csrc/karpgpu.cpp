@@ -276,6 +276,10 @@ struct Compiled {
   size_t state_bytes = 0;
   uint32_t qcap = 0;
   std::vector<uint32_t> queue_order, pod_variant0;  // pods in Queue order; initial variant of every pod
+  // simulations: what every bound pod of the universe adds to the initial topology counts (it is taken out of the
+  // simulations that reschedule it): gcount index g * 64 + d, or 0x80000000 | hcount index
+  std::vector<std::vector<uint32_t>> contrib;
+  std::vector<uint64_t> gdom_univ;   // [G] domains registered from the NodePools / instance types alone
   size_t o_nreq, o_creq, o_chead, o_chstamp, o_cmask, o_cbits, o_cmeta, o_cnpods, o_ctmpl, o_order, o_remaining, o_gcount, o_gdom, o_gpos, o_hcount, o_hpos, o_queue,
       o_podkind, o_excl, o_podindex, o_podreason, o_scratch, o_ordg, o_header, o_counters, o_nqueue;
   ~Compiled() {
@@ -338,6 +342,8 @@ struct SolveInputs {
   const kg_nodepools_desc* nps;
   ParsedPods* pending;
   int sim_cmax = 0;  // > 0: compile for a batch of simulations over subsets of `pending` with at most this many pods each
+  const std::vector<int32_t>* universe_bound = nullptr;  // simulations: bound-pod index of every pod of `pending`, -1 = a pending pod
+  uint32_t n_shared = 0;                                  // simulations: pods [0, n_shared) take part in every simulation
 };
 
 // Builds every device table for one Solve over `in.pending`.
@@ -854,8 +860,6 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   const bool sim_mode = in.sim_cmax > 0;
   const int Cmax = sim_mode ? in.sim_cmax : std::max(P, 1);
   C.Cmax = Cmax;
-  if (sim_mode && G > 0) throw Unsupported("consolidation simulations with topology spread / pod (anti-)affinity are not on the device path yet");
-  if (sim_mode && tmpl_minv_mask) throw Unsupported("consolidation simulations with minValues NodePools are not on the device path yet");
   const int H = N + Cmax;
   std::vector<int32_t> hcount0((size_t)std::max(GH, 1) * H, 0), hpos0(std::max(GH, 1), 0);
   if (G > 0) {
@@ -903,14 +907,25 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
         }
         return false;
       };
-      auto record = [&](int g, const CNode& nd, int cluster_idx) {
+      // Topology.excludedPods = the pods a Solve schedules.  In a batch of simulations the shared pods are excluded
+      // from every simulation; a candidate's pods are counted here and taken out again per simulation (C.contrib).
+      std::vector<int32_t> univ_of_bound(cl->bound.pods.size(), -1);
+      if (in.universe_bound) {
+        C.contrib.resize(in.universe_bound->size());
+        for (size_t u = 0; u < in.universe_bound->size(); ++u) if ((*in.universe_bound)[u] >= 0) univ_of_bound[(*in.universe_bound)[u]] = (int32_t)u;
+      }
+      C.gdom_univ = gdom0;
+      if ((size_t)std::max(GH, 1) * H >= (1ull << 31)) throw Unsupported("hostname topology table over 2^31 entries");
+      auto record = [&](int g, const CNode& nd, int cluster_idx, int32_t u) {
         if (groups[g].key == ctx->kHostname) {
           // hostname domains of nodes outside the scan (deleting) are not tracked
           int pos = pos_of_node[cluster_idx];
           if (pos < 0) return;
-          int32_t& c = hcount0[(size_t)ghidx[g] * H + pos];
+          const size_t idx = (size_t)ghidx[g] * H + pos;
+          int32_t& c = hcount0[idx];
           if (c == 0) hpos0[ghidx[g]]++;
           c++;
+          if (u >= 0) C.contrib[u].push_back(0x80000000u | (uint32_t)idx);
           return;
         }
         for (auto& kv : nd.labels) {
@@ -919,6 +934,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
           gcount0[(size_t)g * 64 + kv.second]++;
           gdom0[g] |= 1ull << kv.second;
           gpos0[g] |= 1ull << kv.second;
+          if (u >= 0) C.contrib[u].push_back((uint32_t)(g * 64 + kv.second));
         }
       };
       for (size_t ci = 0; ci < cl->bound.classes.size(); ++ci) {
@@ -927,13 +943,19 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
           if (groups[g].inverse) continue;
           if (!groups[g].selects(bc)) continue;
           for (uint32_t pi : pods_of_class[ci]) {
+            const int32_t u = univ_of_bound[pi];
+            if (u >= 0 && (uint32_t)u < in.n_shared) continue;
             const CNode& nd = cl->nodes[cl->bound.pods[pi].node];
             if (!node_filter_ok(g, nd)) continue;
-            record(g, nd, cl->bound.pods[pi].node);
+            record(g, nd, cl->bound.pods[pi].node, u);
           }
         }
         for (uint32_t g : bound_inv_owned[ci])
-          for (uint32_t pi : pods_of_class[ci]) record((int)g, cl->nodes[cl->bound.pods[pi].node], cl->bound.pods[pi].node);
+          for (uint32_t pi : pods_of_class[ci]) {
+            const int32_t u = univ_of_bound[pi];
+            if (u >= 0 && (uint32_t)u < in.n_shared) continue;
+            record((int)g, cl->nodes[cl->bound.pods[pi].node], cl->bound.pods[pi].node, u);
+          }
       }
     }
   }
@@ -1135,18 +1157,24 @@ static double cheapest_price(const CatType& t, uint64_t zmask, uint64_t ctmask) 
   }
   return best;
 }
-static bool satisfies_min_values(const kg_catalog* cat, const std::vector<uint32_t>& types, const std::vector<std::pair<uint32_t, int>>& minvals) {
+// InstanceTypes.SatisfiesMinValues; *needed = how many of the (ordered) types it takes
+static bool satisfies_min_values(const kg_catalog* cat, const std::vector<uint32_t>& types, const std::vector<std::pair<uint32_t, int>>& minvals,
+                                 int* needed = nullptr) {
+  if (needed) *needed = 0;
   if (minvals.empty() || types.empty()) return true;
   std::vector<std::set<uint32_t>> seen(minvals.size());
+  int n = 0;
   for (uint32_t t : types) {
     bool ok = true;
+    n++;
     for (size_t i = 0; i < minvals.size(); ++i) {
       const HReq* r = cat->types[t].reqs.find(minvals[i].first);
       if (r) seen[i].insert(r->vals.begin(), r->vals.end());
       if ((int)seen[i].size() < minvals[i].second) ok = false;
     }
-    if (ok) return true;
+    if (ok) { if (needed) *needed = n; return true; }
   }
+  if (needed) *needed = n;
   return false;
 }
 // returns false when minValues breaks under truncation (the caller keeps the ordered, untruncated list)
@@ -1624,7 +1652,8 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   const uint32_t cls_off = (uint32_t)U.classes.size();
   U.classes.insert(U.classes.end(), cluster->bound.classes.begin(), cluster->bound.classes.end());
   std::vector<uint8_t> nonpending;
-  for (auto& p : pend.pods) { U.pods.push_back(p); nonpending.push_back(0); }
+  std::vector<int32_t> universe_bound;
+  for (auto& p : pend.pods) { U.pods.push_back(p); nonpending.push_back(0); universe_bound.push_back(-1); }
   std::vector<std::vector<uint32_t>> pods_of_node(cluster->nodes.size());
   for (size_t i = 0; i < cluster->bound.pods.size(); ++i)
     if (cluster->bound.pods[i].reschedulable) pods_of_node[cluster->bound.pods[i].node].push_back((uint32_t)i);
@@ -1633,6 +1662,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
     pr.cls += cls_off;
     U.pods.push_back(std::move(pr));
     nonpending.push_back(1);
+    universe_bound.push_back((int32_t)bi);
   };
   std::vector<uint8_t> is_cand(cluster->nodes.size(), 0);
   const uint32_t n_used = multi ? std::min<uint32_t>(n, 100) : n;
@@ -1672,6 +1702,8 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   // ---- compile once; every simulation shares the problem tables
   SolveInputs in{ctx, cat, cluster, nodepools, &U};
   in.sim_cmax = cmax;
+  in.universe_bound = &universe_bound;
+  in.n_shared = n_shared;
   auto C = compile_problem(in, false);
   const int N = C->N, NW = std::max((N + 63) / 64, 1), R = C->R, NP = C->NP;
   std::vector<int> pos_of_node(cluster->nodes.size(), -1);
@@ -1694,7 +1726,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   std::vector<SimResult> results(live.size());
   for (size_t b0 = 0; b0 < live.size(); b0 += max_batch) {
     const size_t nb = std::min(max_batch, live.size() - b0);
-    std::vector<uint32_t> q_off(nb + 1, 0), x_off(nb + 1, 0), x_node;
+    std::vector<uint32_t> q_off(nb + 1, 0), x_off(nb + 1, 0), x_node, t_off(nb + 1, 0), t_ent;
     std::vector<uint32_t> q_ent;
     std::vector<int64_t> rem_adj(any_limits ? nb * (size_t)R * NP : 0, 0);
     std::vector<SimState> sims(nb);
@@ -1712,6 +1744,9 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
       q_off[k] = (uint32_t)(q_ent.size() / 4);
       for (uint32_t p : pods) { q_ent.push_back(p); q_ent.push_back(C->pod_variant0[p]); q_ent.push_back(0); q_ent.push_back(0); }
       x_off[k] = (uint32_t)x_node.size();
+      t_off[k] = (uint32_t)t_ent.size();
+      if (!C->contrib.empty())
+        for (uint32_t p = un.pod_lo; p < un.pod_hi; ++p) t_ent.insert(t_ent.end(), C->contrib[p].begin(), C->contrib[p].end());
       const uint32_t c0 = multi ? 0 : un.id, c1 = un.id + 1;
       for (uint32_t ci = c0; ci < c1; ++ci) {
         const int nd = cands->candidates[ci];
@@ -1738,11 +1773,12 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
     }
     q_off[nb] = (uint32_t)(q_ent.size() / 4);
     x_off[nb] = (uint32_t)x_node.size();
+    t_off[nb] = (uint32_t)t_ent.size();
     // one upload for all the per-simulation tables
     Arena PA;
     const size_t o_qoff = PA.add(q_off), o_qent = PA.add(q_ent, 4), o_xoff = PA.add(x_off), o_xnode = PA.add(x_node), o_rem = PA.add(rem_adj),
                  o_nq = PA.reserve(nb * 4), o_res = PA.reserve(nb * sizeof(SimResult)), o_np = PA.add(nonpending), o_un = PA.add(node_uninit),
-                 o_sims = PA.add(sims);
+                 o_sims = PA.add(sims), o_toff = PA.add(t_off), o_tent = PA.add(t_ent), o_guniv = PA.add(C->gdom_univ);
     DeviceBuffer patch;
     patch.bytes = PA.bytes.size();
     patch.ptr = hal::dmalloc(patch.bytes);
@@ -1753,6 +1789,8 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
     B.arena = (uint8_t*)arena.ptr; B.stride = stride; B.o_queue = C->o_queue; B.o_excl = C->o_excl; B.o_remaining = C->o_remaining;
     B.q_off = (const uint32_t*)pp(o_qoff); B.q_ent = (const uint4*)pp(o_qent); B.x_off = (const uint32_t*)pp(o_xoff); B.x_node = (const uint32_t*)pp(o_xnode);
     B.rem_adj = any_limits ? (const int64_t*)pp(o_rem) : nullptr; B.nqueue = (uint32_t*)pp(o_nq); B.results = (SimResult*)pp(o_res);
+    B.t_off = C->G > 0 ? (const uint32_t*)pp(o_toff) : nullptr; B.t_ent = (const uint32_t*)pp(o_tent); B.gdom_univ = (const uint64_t*)pp(o_guniv);
+    B.o_gcount = C->o_gcount; B.o_gdom = C->o_gdom; B.o_gpos = C->o_gpos; B.o_hcount = C->o_hcount; B.o_hpos = C->o_hpos;
     B.pod_nonpending = (const uint8_t*)pp(o_np); B.node_uninit = (const uint64_t*)pp(o_un); B.nsims = (int)nb;
     float ms_i = 0, ms_s = 0, ms_g = 0;
     hal::launch_sim_init(C->dp, B, &ms_i);
@@ -1805,18 +1843,35 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
       bool priced = true, all_spot = true;
       double price = 0;
       for (uint32_t ci = c0; ci < c1; ++ci) { priced &= cinfo[ci].ok; price += cinfo[ci].price; all_spot &= cinfo[ci].spot; }
+      // Results.TruncateInstanceTypes comes before any price: the claim's options in price order, cut to the maximum,
+      // minValues (the merged requirements of the claim carry its NodePool's) checked on what is left
+      rp.nodepool = C->templates[sr.tmpl].index;
+      rp.zmask = allowed1(sr.zone_meta, sr.zone_word);
+      rp.ctmask = allowed1(sr.ct_meta, sr.ct_word);
+      const uint64_t zidm = allowed1(sr.zid_meta, sr.zid_word);
+      if (sr.zid_meta & RM_PRESENT)
+        for (int z = 0; z < 64; ++z) if (zone_zid[z] != 0xFF && !((zidm >> zone_zid[z]) & 1)) rp.zmask &= ~(1ull << z);
+      for (int w = 0; w < C->TW && w < KG_TWLDS; ++w)
+        for (uint64_t m = sr.mask[w]; m; m &= m - 1) rp.types.push_back((uint32_t)(w * 64 + __builtin_ctzll(m)));
+      order_by_price(cat, &rp.types, rp.zmask, rp.ctmask);
+      std::vector<std::pair<uint32_t, int>> mv;
+      for (auto& q : C->templates[sr.tmpl].reqs.rs) if (q.min_values >= 0) mv.push_back({q.key, q.min_values});
+      if (nodepools->max_instance_types > 0) {
+        std::vector<uint32_t> trunc(rp.types.begin(), rp.types.begin() + std::min<size_t>(rp.types.size(), (size_t)nodepools->max_instance_types));
+        if (!mv.empty() && !satisfies_min_values(cat, trunc, mv)) {
+          // the claim is dropped and its pods fail: a rescheduled pod among them vetoes the command, otherwise no claim is left
+          rp.types.clear();
+          if (!sr.pad) rp.decision = KG_DECISION_DELETE;
+          priced = false;
+        } else rp.types.swap(trunc);
+      }
+      auto price_filter = [&](double max_price) {  // NodeClaim.RemoveInstanceTypeOptionsByPriceAndMinValues
+        remove_by_price(cat, &rp, max_price, spot, od);
+        return mv.empty() || satisfies_min_values(cat, rp.types, mv);
+      };
       if (priced) {
         rp.candidate_price = price;
-        rp.nodepool = C->templates[sr.tmpl].index;
-        rp.zmask = allowed1(sr.zone_meta, sr.zone_word);
-        rp.ctmask = allowed1(sr.ct_meta, sr.ct_word);
-        const uint64_t zidm = allowed1(sr.zid_meta, sr.zid_word);
-        if (sr.zid_meta & RM_PRESENT)
-          for (int z = 0; z < 64; ++z) if (zone_zid[z] != 0xFF && !((zidm >> zone_zid[z]) & 1)) rp.zmask &= ~(1ull << z);
-        for (int w = 0; w < C->TW && w < KG_TWLDS; ++w)
-          for (uint64_t m = sr.mask[w]; m; m &= m - 1) rp.types.push_back((uint32_t)(w * 64 + __builtin_ctzll(m)));
-        order_by_price(cat, &rp.types, rp.zmask, rp.ctmask);
-        if (nodepools->max_instance_types > 0 && rp.types.size() > (size_t)nodepools->max_instance_types) rp.types.resize(nodepools->max_instance_types);
+        {
         const bool has_spot = spot >= 0 && ((rp.ctmask >> spot) & 1), has_od = od >= 0 && ((rp.ctmask >> od) & 1);
         if (all_spot && has_spot) {
           // computeSpotToSpotConsolidation
@@ -1825,15 +1880,20 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
             std::vector<uint32_t> compat;
             for (uint32_t t : rp.types) if (cheapest_price(cat->types[t], rp.zmask, rp.ctmask) != std::numeric_limits<double>::max()) compat.push_back(t);
             rp.types.swap(compat);
-            remove_by_price(cat, &rp, price, spot, od);
+            if (!price_filter(price)) rp.types.clear();
             rp.spot_only = true;
             if (!rp.types.empty()) {
               if (c1 - c0 > 1) rp.decision = KG_DECISION_REPLACE;
-              else if (rp.types.size() >= 15) { rp.types.resize(15); rp.decision = KG_DECISION_REPLACE; }
+              else if (rp.types.size() >= 15) {
+                int keep = 15, need = 0;  // MinInstanceTypesForSpotToSpotConsolidation, or what minValues needs
+                if (!mv.empty()) { satisfies_min_values(cat, rp.types, mv, &need); keep = std::max(keep, need); }
+                if ((int)rp.types.size() > keep) rp.types.resize(keep);
+                rp.decision = KG_DECISION_REPLACE;
+              }
             }
           }
         } else {
-          remove_by_price(cat, &rp, price, spot, od);
+          if (!price_filter(price)) rp.types.clear();
           if (!rp.types.empty()) {
             if (has_spot && has_od) { rp.ctmask = 1ull << spot; rp.spot_only = true; }
             rp.decision = KG_DECISION_REPLACE;
@@ -1845,8 +1905,9 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
           for (uint32_t t : rp.types)
             for (uint32_t ci = c0; ci < c1; ++ci)
               if (cinfo[ci].ok && cinfo[ci].type == (int)t && cinfo[ci].price < max_price) max_price = cinfo[ci].price;
-          remove_by_price(cat, &rp, max_price, spot, od);
+          remove_by_price(cat, &rp, max_price, spot, od);  // (its minValues error is swallowed upstream)
           if (rp.types.empty()) rp.decision = KG_DECISION_NOOP;
+        }
         }
       }
     }

@@ -1393,7 +1393,7 @@ struct SimResult {
   uint32_t errors;           // non-pending pods left unschedulable or placed on a node that is not initialised
   uint32_t tmpl;             // template (nodepool, weight order) of claim 0
   uint32_t n_pods;
-  uint32_t zone_meta, ct_meta, zid_meta, pad;
+  uint32_t zone_meta, ct_meta, zid_meta, pad;  // pad: claim 0 holds a pod that is being rescheduled (not a pending pod)
   uint64_t zone_word, ct_word, zid_word;
   uint64_t mask[KG_TWLDS];   // option mask of claim 0 (<= 1024 types)
 };
@@ -1407,6 +1407,10 @@ struct SimBatch {
   const uint32_t* x_off;     // [nsims + 1] -> x_node
   const uint32_t* x_node;    // scan positions of the candidate nodes of every simulation
   const int64_t* rem_adj;    // [nsims][R * NP] limits given back by the candidates (null when no NodePool has limits)
+  const uint32_t* t_off;     // [nsims + 1] -> t_ent (null when the problem has no topology groups)
+  const uint32_t* t_ent;     // topology counts of the simulation's own bound pods: gcount index, or 0x80000000 | hcount index
+  const uint64_t* gdom_univ; // [G] domains registered without any pod
+  unsigned long long o_gcount, o_gdom, o_gpos, o_hcount, o_hpos;
   uint32_t* nqueue;          // [nsims]
   SimResult* results;        // [nsims]
   const uint8_t* pod_nonpending;  // [P] 1 = bound pod being rescheduled (must schedule), 0 = pending pod
@@ -1433,6 +1437,25 @@ KG_HD void sim_init_patch(const DevProblem& P, const SimBatch& B, uint32_t i, ui
       int64_t* rem = (int64_t*)(slot + B.o_remaining);
       for (int k = 0; k < P.R * P.NP; ++k) if (rem[k] != 0x7FFFFFFFFFFFFFFFll) rem[k] += B.rem_adj[(size_t)i * P.R * P.NP + k];
     }
+    if (B.t_off) {
+      // Topology.excludedPods: the pods this simulation reschedules do not count in the initial domains
+      int32_t* gc = (int32_t*)(slot + B.o_gcount);
+      uint64_t* gdom = (uint64_t*)(slot + B.o_gdom);
+      uint64_t* gpos = (uint64_t*)(slot + B.o_gpos);
+      int32_t* hc = (int32_t*)(slot + B.o_hcount);
+      int32_t* hpos = (int32_t*)(slot + B.o_hpos);
+      for (uint32_t k = B.t_off[i]; k < B.t_off[i + 1]; ++k) {
+        const uint32_t e = B.t_ent[k];
+        if (e >> 31) {
+          const uint32_t idx = e & 0x7FFFFFFFu;
+          if (--hc[idx] == 0) hpos[idx / (uint32_t)P.H] -= 1;
+        } else if (--gc[e] == 0) {
+          const uint32_t g = e >> 6, d = e & 63;
+          gpos[g] &= ~(1ull << d);
+          if (!((B.gdom_univ[g] >> d) & 1)) gdom[g] &= ~(1ull << d);
+        }
+      }
+    }
   }
 }
 
@@ -1441,18 +1464,20 @@ KG_HD void sim_gather(const DevProblem& P, const SimBatch& B, const SimState& S,
   SimResult r;
   r.nclaims = S.header[0];
   r.errors = 0;
+  uint32_t claim0_np = 0;
   for (uint32_t k = B.q_off[i]; k < B.q_off[i + 1]; ++k) {
     const uint32_t pod = B.q_ent[k].x;
     if (!B.pod_nonpending[pod]) continue;
     const uint32_t row = pod_row(S, pod);
     const uint8_t kind = S.pod_kind[row];
+    if (kind == 2 && S.pod_index[row] == 0) claim0_np = 1;
     if (kind == 0) r.errors++;
     else if (kind == 1) {
       const uint32_t n = (uint32_t)S.pod_index[row];
       if ((B.node_uninit[n >> 6] >> (n & 63)) & 1) r.errors++;
     }
   }
-  r.tmpl = 0; r.n_pods = 0; r.zone_meta = r.ct_meta = r.zid_meta = 0; r.pad = 0; r.zone_word = r.ct_word = r.zid_word = 0;
+  r.tmpl = 0; r.n_pods = 0; r.zone_meta = r.ct_meta = r.zid_meta = 0; r.pad = claim0_np; r.zone_word = r.ct_word = r.zid_word = 0;
   for (int w = 0; w < KG_TWLDS; ++w) r.mask[w] = 0;
   if (r.nclaims == 1) {
     r.tmpl = S.c_tmpl[0];

@@ -24,14 +24,43 @@ def cluster(name, n):
             if i % 3 == 0:
                 nd["initialized"] = False
         return types, nodes, bound, []
+    if name == "topology":
+        # bound pods carry the constraints their deployments would: zone spread, hostname spread, required hostname
+        # anti-affinity, required zone affinity -- by app label, a quarter of the apps each
+        nodes, bound = wl.dense_cluster(n, 17, types, zones, lo=0.4, hi=0.9)
+        for p in bound:
+            app = p["labels"]["app"]
+            sel = {"match_labels": {"app": app}}
+            kind = int(app[-2:]) % 4
+            if kind == 0:
+                p["spreads"] = [{"key": wl.L_ZONE, "max_skew": 2, "when": "DoNotSchedule", "selector": sel}]
+            elif kind == 1:
+                p["spreads"] = [{"key": wl.L_HOSTNAME, "max_skew": 3, "when": "DoNotSchedule", "selector": sel}]
+            elif kind == 2:
+                p["anti_affinity_required"] = [{"key": wl.L_HOSTNAME, "selector": sel}]
+            else:
+                p["affinity_required"] = [{"key": wl.L_ZONE, "selector": sel}]
+        return types, nodes, bound, []
     raise KeyError(name)
 
 
+def nodepool_for(name):
+    """NodePool of a named consolidation scenario: minValues on the instance family, loose / binding / beyond the 60-type cut."""
+    G = "karpenter.k8s.aws"
+    if name == "minvalues_loose":
+        return wl.default_nodepool(extra_reqs=[(G + "/instance-family", "Exists", [], 3)])
+    if name == "minvalues_tight":
+        return wl.default_nodepool(extra_reqs=[(G + "/instance-family", "Exists", [], 12)])
+    if name in ("minvalues_trunc", "minvalues_trunc_pending"):
+        return wl.default_nodepool(extra_reqs=[("node.kubernetes.io/instance-type", "Exists", [], 70)])
+    return wl.default_nodepool()
+
+
 def check_consolidation(L, name, n, spot_to_spot, n_shards=3):
-    types, nodes, bound, pending = cluster(name, n)
+    types, nodes, bound, pending = cluster(("dense_pending" if name.endswith("_pending") else "dense") if name.startswith("minvalues") else name, n)
     order = wl.disruption_order(nodes, bound)
     cat, cl = abi.build_catalog(types), abi.build_cluster(nodes, bound)
-    pend, nps = abi.build_pods(pending), abi.build_nodepools([wl.default_nodepool()], wl.WELL_KNOWN_LABELS)
+    pend, nps = abi.build_pods(pending), abi.build_nodepools([nodepool_for(name)], wl.WELL_KNOWN_LABELS)
     hcat, hcl = L.catalog_upload(cat), L.cluster_upload(cl)
     seen = set()
     try:
