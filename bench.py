@@ -42,6 +42,26 @@ def pmc_traffic(n_pods):
         return json.load(f).get("k_solve_traffic_bytes")
 
 
+def measured_copy_gbs(torch):
+    """Device-to-device stream copy on this box (the second roofline denominator): 1 GiB, read + write."""
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device="cuda")
+    b = torch.empty_like(a)
+    a.fill_(1.0)
+    for _ in range(2):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    del a, b
+    return 2.0 * n * 4 / (ms * 1e-3) / 1e9
+
+
 def bench_consolidation(args, L, hcat, types, zones, world, rank, barrier, dist, torch):
     """C4: consolidation on a synthetic cluster (seed 11), single- and multi-node, units sharded over the ranks."""
     from karpenter_amd import abi, distributed, workloads as wl
@@ -150,6 +170,7 @@ def main():
         cons = bench_consolidation(args, L, hcat, types, zones, world, rank, barrier, dist, torch)
 
     if rank == 0:
+        copy_gbs = measured_copy_gbs(torch)
         ms_per_step = dt * 1000.0 / args.steps
         value = args.pods * world * args.steps / dt
         k_ms = sum(solve_ms) / len(solve_ms)
@@ -164,6 +185,7 @@ def main():
                              "k_solve": k_ms, "host_decode_truncate": sum(decode_ms) / len(decode_ms)},
             "roofline": {"bound": "hbm", "kernel": "k_solve", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.pods),
+                         "peak_measured_copy": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "rows the reference algorithm visits up to its first feasible index (SURVEY.md 8d): "
                                  "212 B/existing node, 400 B/NodeClaim, 336 B/instance type"},

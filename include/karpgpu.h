@@ -352,6 +352,7 @@ typedef struct {
   uint64_t solves, pods, kernel_launches;
   double device_ms_total, host_compile_ms_total;
   uint64_t device_bytes_resident;
+  uint64_t catalog_words_patched; /* 8-byte words of resident catalogs rewritten in place by kg_catalog_update_offerings */
 } kg_stats;
 
 typedef struct kg_ctx kg_ctx;
@@ -381,6 +382,22 @@ int32_t kg_catalog_build_ec2(kg_ctx* ctx, const kg_ec2_catalog_desc* desc, uint6
 int32_t kg_catalog_query(kg_catalog* cat, uint32_t type_index, const char* const* resource_names, uint32_t n,
                          int64_t* capacity_milli, int64_t* allocatable_milli, char* name_buf, size_t name_cap);
 int32_t kg_catalog_size(kg_catalog* cat, uint32_t* n_types, uint64_t* generation);
+/* In-place maintenance of a resident catalog: replaces re-running DefaultProvider.List after an
+ * ICE mark (pkg/cache/unavailableofferings.go:55-65 bumps SeqNum, which is part of the cache key of
+ * instancetype.go:127-136) or a spot price refresh (pkg/providers/pricing/pricing.go:357-400).  Every update names an
+ * EXISTING offering (type, zone, capacity type) and sets its availability and/or price, exactly what createOfferings
+ * (instancetype.go:264-315) would recompute for it.  The zone / capacity-type / zone-id requirements of the touched
+ * types are re-derived from their available offerings (types.go:80-88, 112-117) and only the changed words of the
+ * device tables are rewritten.  `generation` becomes the catalog's new cache key. */
+typedef struct {
+  uint32_t type_index;
+  uint32_t zone;           /* string ids into the strtab passed with the call */
+  uint32_t capacity_type;
+  int32_t available;       /* 0 / 1; -1 = leave as it is */
+  double price;            /* < 0 = leave as it is */
+} kg_offering_update;
+int32_t kg_catalog_update_offerings(kg_ctx* ctx, kg_catalog* cat, const kg_strtab* strings, const kg_offering_update* updates, uint32_t n_updates,
+                                    uint64_t generation);
 int32_t kg_catalog_free(kg_catalog* cat);
 
 int32_t kg_cluster_upload(kg_ctx* ctx, const kg_cluster_desc* desc, kg_cluster** out);

@@ -59,6 +59,7 @@ SUBNET = np.dtype([("zone", "<u4"), ("zone_id", "<u4")], align=True)
 SPOT_PRICE = np.dtype([("instance_type", "<u4"), ("zone", "<u4"), ("price", "<f8")], align=True)
 OD_PRICE = np.dtype([("instance_type", "<u4"), ("price", "<f8")], align=True)
 UNAVAILABLE = np.dtype([("capacity_type", "<u4"), ("instance_type", "<u4"), ("zone", "<u4")], align=True)
+OFFERING_UPDATE = np.dtype([("type_index", "<u4"), ("zone", "<u4"), ("capacity_type", "<u4"), ("available", "<i4"), ("price", "<f8")], align=True)
 
 # name -> dtype, in the order kg_abi_sizes() reports them
 ABI_ELEMENTS = [("kg_range", RANGE), ("kg_requirement", REQUIREMENT), ("kg_quantity", QUANTITY), ("kg_label", LABEL), ("kg_taint", TAINT),
@@ -66,7 +67,7 @@ ABI_ELEMENTS = [("kg_range", RANGE), ("kg_requirement", REQUIREMENT), ("kg_quant
                 ("kg_spread", SPREAD), ("kg_pod_affinity_term", AFFINITY_TERM), ("kg_weighted_term", WEIGHTED_TERM), ("kg_host_port", HOST_PORT),
                 ("kg_pod", POD), ("kg_node", NODE), ("kg_nodepool", NODEPOOL), ("kg_claim_out", CLAIM_OUT), ("kg_req_out", REQ_OUT),
                 ("kg_candidate_record", CANDIDATE_RECORD), ("kg_ec2_device", EC2_DEVICE), ("kg_ec2_type", EC2_TYPE), ("kg_subnet", SUBNET),
-                ("kg_spot_price", SPOT_PRICE), ("kg_od_price", OD_PRICE), ("kg_unavailable", UNAVAILABLE)]
+                ("kg_spot_price", SPOT_PRICE), ("kg_od_price", OD_PRICE), ("kg_unavailable", UNAVAILABLE), ("kg_offering_update", OFFERING_UPDATE)]
 
 P = C.c_void_p
 
@@ -149,7 +150,7 @@ class CandidatesDesc(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("solves", C.c_uint64), ("pods", C.c_uint64), ("kernel_launches", C.c_uint64), ("device_ms_total", C.c_double),
-                ("host_compile_ms_total", C.c_double), ("device_bytes_resident", C.c_uint64)]
+                ("host_compile_ms_total", C.c_double), ("device_bytes_resident", C.c_uint64), ("catalog_words_patched", C.c_uint64)]
 
 
 def _ptr(a):
@@ -423,6 +424,15 @@ class ResultBuffers:
                 claim["requirements"] = reqs
             out["claims"].append(claim)
         return out
+
+
+def build_offering_updates(updates):
+    """updates: iterable of (type_index, zone, capacity_type, available or None, price or None) -> (Built(StrTab), array)."""
+    pb = _PoolBuilder()
+    rows = [(int(t), pb.s(z), pb.s(ct), -1 if av is None else int(bool(av)), -1.0 if pr is None else float(pr)) for t, z, ct, av, pr in updates]
+    pools = pb.finish()
+    a = np.array(rows, dtype=OFFERING_UPDATE) if rows else np.zeros(0, OFFERING_UPDATE)
+    return Built(pools.strings, [pb, pools]), a
 
 
 def build_candidates(candidates, spot_to_spot=False, shard=0, n_shards=1):

@@ -8,6 +8,7 @@
 //   twv     per (key, value): types whose requirement on key contains value
 //   kU/kN   per key: types that list the key as DoesNotExist / do not mention it
 //   offmask per (zone, capacity-type): types with an AVAILABLE offering there (instancetype.go:289)
+#include <set>
 #include "ctx.hpp"
 
 namespace kg {
@@ -178,6 +179,90 @@ void build_catalog_tables(kg_ctx* ctx, kg_catalog* cat) {
   C.dev.ptr = hal::dmalloc(C.dev.bytes);
   hal::h2d(C.dev.ptr, A.bytes.data(), C.dev.bytes);
   ctx->stats.device_bytes_resident += C.dev.bytes;
+}
+
+// In-place maintenance (kg_catalog_update_offerings): host model first, then the words of the device tables that differ.
+void update_offerings(kg_ctx* ctx, kg_catalog* cat, const kg_strtab& strings, const kg_offering_update* ups, uint32_t n) {
+  Vocab& V = ctx->V;
+  CatalogTables& C = cat->tab;
+  const uint32_t keys3[3] = {ctx->kZone, ctx->kCT, ctx->kZid};
+  // validate everything before touching anything
+  struct Hit { uint32_t t; size_t o; };
+  std::vector<Hit> hits;
+  for (uint32_t i = 0; i < n; ++i) {
+    const kg_offering_update& u = ups[i];
+    kgdesc::check(u.type_index < cat->types.size(), "offering update: type index");
+    const int z = V.vals[ctx->kZone].find(std::string(kgdesc::str(strings, u.zone))), c = V.vals[ctx->kCT].find(std::string(kgdesc::str(strings, u.capacity_type)));
+    size_t found = SIZE_MAX;
+    const auto& offs = cat->types[u.type_index].offerings;
+    for (size_t o = 0; o < offs.size(); ++o) if ((int)offs[o].zone == z && (int)offs[o].ct == c) found = o;
+    kgdesc::check(found != SIZE_MAX, "offering update names an offering the catalog does not have");
+    hits.push_back({u.type_index, found});
+  }
+  const bool resident = C.dev.ptr != nullptr;
+  const uint32_t tw = C.TW;
+  std::vector<size_t> dirty;  // byte offsets of 8-byte words of the image that changed
+  auto set_bit = [&](size_t word_off, uint32_t t, bool on) {
+    if (!resident) return;
+    uint64_t* w = (uint64_t*)(C.image.bytes.data() + word_off) + (t >> 6);
+    const uint64_t nv = on ? (*w | (1ull << (t & 63))) : (*w & ~(1ull << (t & 63)));
+    if (nv != *w) { *w = nv; dirty.push_back(word_off + (size_t)(t >> 6) * 8); }
+  };
+  std::vector<uint32_t> touched;
+  for (uint32_t i = 0; i < n; ++i) {
+    CatOffering& o = cat->types[hits[i].t].offerings[hits[i].o];
+    if (ups[i].available >= 0) o.available = ups[i].available != 0;
+    if (ups[i].price >= 0) o.price = ups[i].price;
+    touched.push_back(hits[i].t);
+  }
+  std::sort(touched.begin(), touched.end());
+  touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+  for (uint32_t t : touched) {
+    CatType& ty = cat->types[t];
+    // offering availability per (zone, capacity type)
+    std::set<std::pair<uint32_t, uint32_t>> avail;
+    for (auto& o : ty.offerings) if (o.available) avail.insert({o.zone, o.ct});
+    for (auto& o : ty.offerings) set_bit(C.o_offmask + ((size_t)o.zone * 4 + o.ct) * tw * 8, t, avail.count({o.zone, o.ct}) != 0);
+    // computeRequirements: zone / capacity-type / zone-id In {values of the available offerings}
+    for (int k3 = 0; k3 < 3; ++k3) {
+      const uint32_t key = keys3[k3];
+      HReq* cur = nullptr;
+      for (auto& r : ty.reqs.rs) if (r.key == key) cur = &r;
+      if (!cur) continue;  // a type that never mentioned the key keeps not mentioning it
+      std::vector<uint32_t> vals;
+      for (auto& o : ty.offerings) {
+        if (!o.available) continue;
+        if (k3 == 0) vals.push_back(o.zone);
+        else if (k3 == 1) vals.push_back(o.ct);
+        else if (o.zid >= 0) vals.push_back((uint32_t)o.zid);
+      }
+      std::sort(vals.begin(), vals.end());
+      vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+      cur->vals = vals;
+      if (key < C.key_row_off.size() && C.key_row_off[key] != UINT32_MAX) {
+        for (uint32_t v = 0; v < C.key_nvals[key]; ++v)
+          set_bit(C.o_twv + ((size_t)C.key_row_off[key] + v) * tw * 8, t, std::binary_search(vals.begin(), vals.end(), v));
+        // a requirement left without values reads as DoesNotExist
+        uint64_t& ku = C.kU[key][t >> 6];
+        if (vals.empty()) ku |= 1ull << (t & 63); else ku &= ~(1ull << (t & 63));
+      }
+    }
+    // prices / availability columns of the offering table
+    if (resident) {
+      const uint32_t* off_begin = (const uint32_t*)(C.image.bytes.data() + C.o_off_begin);
+      for (size_t oi = 0; oi < ty.offerings.size(); ++oi) {
+        const size_t row = off_begin[t] + oi;
+        double* pr = (double*)(C.image.bytes.data() + C.o_off_price) + row;
+        uint8_t* av = C.image.bytes.data() + C.o_off_avail + row;
+        if (*pr != ty.offerings[oi].price) { *pr = ty.offerings[oi].price; dirty.push_back(C.o_off_price + row * 8); }
+        if (*av != (uint8_t)ty.offerings[oi].available) { *av = ty.offerings[oi].available; dirty.push_back((C.o_off_avail + row) & ~size_t(7)); }
+      }
+    }
+  }
+  std::sort(dirty.begin(), dirty.end());
+  dirty.erase(std::unique(dirty.begin(), dirty.end()), dirty.end());
+  for (size_t off : dirty) hal::h2d((uint8_t*)C.dev.ptr + off, C.image.bytes.data() + off, std::min<size_t>(8, C.image.bytes.size() - off));
+  ctx->stats.catalog_words_patched += dirty.size();
 }
 
 }  // namespace kg

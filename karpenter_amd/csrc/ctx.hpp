@@ -26,4 +26,5 @@ HReqs parse_reqs(Vocab& V, const kg_pools& p, kg_range r);
 std::vector<std::pair<uint32_t, int64_t>> parse_rl(Vocab& V, const kg_pools& p, kg_range r);
 void parse_catalog(kg_ctx* ctx, const kg_catalog_desc* d, kg_catalog* cat);
 void build_catalog_tables(kg_ctx* ctx, kg_catalog* cat);
+void update_offerings(kg_ctx* ctx, kg_catalog* cat, const kg_strtab& strings, const kg_offering_update* ups, uint32_t n);
 }  // namespace kg

@@ -1271,7 +1271,7 @@ int32_t kg_abi_sizes(uint32_t* out, uint32_t cap) {
                         sizeof(kg_selector), sizeof(kg_offering), sizeof(kg_instance_type), sizeof(kg_spread), sizeof(kg_pod_affinity_term),
                         sizeof(kg_weighted_term), sizeof(kg_host_port), sizeof(kg_pod), sizeof(kg_node), sizeof(kg_nodepool), sizeof(kg_claim_out),
                         sizeof(kg_req_out), sizeof(kg_candidate_record), sizeof(kg_ec2_device), sizeof(kg_ec2_type), sizeof(kg_subnet),
-                        sizeof(kg_spot_price), sizeof(kg_od_price), sizeof(kg_unavailable)};
+                        sizeof(kg_spot_price), sizeof(kg_od_price), sizeof(kg_unavailable), sizeof(kg_offering_update)};
   const uint32_t n = sizeof(s) / sizeof(s[0]);
   for (uint32_t i = 0; i < n && i < cap; ++i) out[i] = s[i];
   return (int32_t)n;
@@ -1318,6 +1318,17 @@ int32_t kg_catalog_query(kg_catalog* cat, uint32_t type_index, const char* const
     name_buf[m] = 0;
   }
   return KG_OK;
+}
+
+int32_t kg_catalog_update_offerings(kg_ctx* ctx, kg_catalog* cat, const kg_strtab* strings, const kg_offering_update* updates, uint32_t n_updates,
+                                    uint64_t generation) {
+  if (!ctx || !cat || cat->ctx != ctx || !strings || (!updates && n_updates)) return KG_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  KG_GUARD_BEGIN
+  update_offerings(ctx, cat, *strings, updates, n_updates);
+  cat->generation = generation;
+  return KG_OK;
+  KG_GUARD_END(ctx)
 }
 
 int32_t kg_catalog_free(kg_catalog* cat) {

@@ -12,7 +12,7 @@ from . import abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_PATH = os.path.join(_HERE, "libkarpgpu.so")
 
-EXPORTS = ["kg_init", "kg_destroy", "kg_last_error", "kg_stats_get", "kg_catalog_upload", "kg_catalog_build_ec2",
+EXPORTS = ["kg_init", "kg_destroy", "kg_last_error", "kg_stats_get", "kg_catalog_upload", "kg_catalog_build_ec2", "kg_catalog_update_offerings",
            "kg_catalog_query", "kg_catalog_size", "kg_catalog_free", "kg_cluster_upload", "kg_cluster_free", "kg_solve",
            "kg_truncate", "kg_launch_filter", "kg_consolidate_single", "kg_consolidate_multi", "kg_consolidate_select"]
 
@@ -35,6 +35,7 @@ class Library:
         d.kg_destroy.argtypes = [C.c_void_p]
         d.kg_catalog_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
         d.kg_catalog_free.argtypes = [C.c_void_p]
+        d.kg_catalog_update_offerings.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64]
         d.kg_catalog_build_ec2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
         d.kg_catalog_query.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
         d.kg_catalog_size.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
@@ -90,6 +91,16 @@ class Library:
         if st != 0:
             raise KgError(st, "kg_catalog_query")
         return name.value.decode(), dict(zip(resources, cap)), dict(zip(resources, alloc))
+
+    def catalog_update_offerings(self, catalog, updates, generation):
+        """updates: iterable of (type_index, zone, capacity_type, available or None, price or None)."""
+        strtab, arr = abi.build_offering_updates(updates)
+        self._check(self.dll.kg_catalog_update_offerings(self.ctx, catalog, C.addressof(strtab.desc), abi._ptr(arr), arr.shape[0], generation))
+
+    def stats(self):
+        st = abi.Stats()
+        self._check(self.dll.kg_stats_get(self.ctx, C.byref(st)))
+        return st
 
     def catalog_size(self, catalog):
         n, g = C.c_uint32(0), C.c_uint64(0)

