@@ -402,6 +402,20 @@ int32_t kg_catalog_free(kg_catalog* cat);
 
 int32_t kg_cluster_upload(kg_ctx* ctx, const kg_cluster_desc* desc, kg_cluster** out);
 int32_t kg_cluster_free(kg_cluster* cl);
+/* The step before the consolidation path (designs/consolidation.md:25-42, website
+ * concepts/disruption.md:17-19): which state nodes are consolidation candidates, their disruption cost
+ *   sum over the node's bound pods of clamp(1 + deletionCost / 2^27 + priority / 2^25, -10, 10) * lifetimeRemaining
+ * and the candidate order (ascending cost; ties keep node order).  A node is a candidate when it is initialised, managed
+ * by a NodePool (nodepool label present), not deleting, carries an instance-type label that `catalog` resolves (skipped
+ * when catalog is NULL) and is not `blocked` (nominated / blocking PDB / do-not-disrupt pod: the controller's checks).
+ * out_nodes receives node indices of the uploaded cluster, ready for kg_candidates_desc.candidates. */
+typedef struct {
+  const double* lifetime_remaining; /* [n_nodes] clamp(1 - age / expireAfter, 0, 1); NULL = 1 everywhere */
+  const uint8_t* blocked;           /* [n_nodes]; NULL = none */
+  uint32_t n_nodes;                 /* must equal the uploaded cluster's node count when either array is given */
+} kg_candidate_inputs;
+int32_t kg_candidates_order(kg_ctx* ctx, kg_catalog* catalog, kg_cluster* cluster, const kg_candidate_inputs* in, int32_t* out_nodes,
+                            double* out_costs /* may be NULL */, uint32_t cap, uint32_t* n_out);
 
 /* Scheduler.Solve + Results.TruncateInstanceTypes for one batch of pending pods. */
 int32_t kg_solve(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, kg_cluster* cluster /* may be NULL */,

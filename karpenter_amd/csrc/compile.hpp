@@ -45,6 +45,7 @@ struct PodRef {
   int64_t creation;
   int node;
   bool reschedulable;
+  int32_t priority = 0, deletion_cost = 0;
 };
 
 struct ParsedPods {

@@ -3,6 +3,7 @@
 #include <chrono>
 #include <cmath>
 #include <limits>
+#include <unordered_set>
 
 #include "compile.hpp"
 
@@ -168,6 +169,8 @@ void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out, bool add_po
     pr.creation = q.creation_ts;
     pr.node = q.node;
     pr.reschedulable = q.reschedulable != 0;
+    pr.priority = q.priority;
+    pr.deletion_cost = q.deletion_cost;
     out->pods.push_back(std::move(pr));
   }
 }
@@ -1379,6 +1382,45 @@ int32_t kg_cluster_upload(kg_ctx* ctx, const kg_cluster_desc* desc, kg_cluster**
 int32_t kg_cluster_free(kg_cluster* cl) {
   delete cl;
   return KG_OK;
+}
+
+int32_t kg_candidates_order(kg_ctx* ctx, kg_catalog* catalog, kg_cluster* cluster, const kg_candidate_inputs* in, int32_t* out_nodes,
+                            double* out_costs, uint32_t cap, uint32_t* n_out) {
+  if (!ctx || !cluster || !n_out || (!out_nodes && cap)) return KG_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  KG_GUARD_BEGIN
+  const size_t N = cluster->nodes.size();
+  if (in && (in->lifetime_remaining || in->blocked)) check(in->n_nodes == N, "candidate inputs: node count");
+  // disruption cost: bound pods in descriptor order (the order fixes the floating-point sum)
+  std::vector<double> cost(N, 0.0);
+  for (auto& p : cluster->bound.pods) {
+    if (p.node < 0 || (size_t)p.node >= N) continue;
+    double c = 1.0 + (double)p.deletion_cost / 134217728.0 + (double)p.priority / 33554432.0;
+    c = std::max(-10.0, std::min(10.0, c));
+    cost[p.node] += c;
+  }
+  std::unordered_set<std::string> names;
+  if (catalog) for (auto& t : catalog->types) names.insert(t.name);
+  std::vector<int32_t> order;
+  for (size_t i = 0; i < N; ++i) {
+    const CNode& nd = cluster->nodes[i];
+    if (in && in->lifetime_remaining) cost[i] *= in->lifetime_remaining[i];
+    if (!nd.initialized || !nd.managed || nd.deleting) continue;
+    if (in && in->blocked && in->blocked[i]) continue;
+    bool has_pool = false, has_type = false, type_ok = !catalog;
+    for (auto& kv : nd.labels) {
+      if (kv.first == ctx->kNodePool) has_pool = true;
+      if (kv.first == ctx->kInstanceType) { has_type = true; if (catalog) type_ok = names.count(ctx->V.vals[ctx->kInstanceType].strs[kv.second]) != 0; }
+    }
+    if (!has_pool || !has_type || !type_ok) continue;
+    order.push_back((int32_t)i);
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cost[a] < cost[b]; });
+  *n_out = (uint32_t)order.size();
+  if (order.size() > cap) return fail(ctx, KG_ENOMEM, "candidate buffer too small");
+  for (size_t k = 0; k < order.size(); ++k) { out_nodes[k] = order[k]; if (out_costs) out_costs[k] = cost[order[k]]; }
+  return KG_OK;
+  KG_GUARD_END(ctx)
 }
 
 int32_t kg_solve(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, kg_cluster* cluster, const kg_pods_desc* pods,

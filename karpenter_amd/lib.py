@@ -12,7 +12,7 @@ from . import abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_PATH = os.path.join(_HERE, "libkarpgpu.so")
 
-EXPORTS = ["kg_init", "kg_destroy", "kg_last_error", "kg_stats_get", "kg_catalog_upload", "kg_catalog_build_ec2", "kg_catalog_update_offerings",
+EXPORTS = ["kg_init", "kg_destroy", "kg_last_error", "kg_stats_get", "kg_catalog_upload", "kg_catalog_build_ec2", "kg_catalog_update_offerings", "kg_candidates_order",
            "kg_catalog_query", "kg_catalog_size", "kg_catalog_free", "kg_cluster_upload", "kg_cluster_free", "kg_solve",
            "kg_truncate", "kg_launch_filter", "kg_consolidate_single", "kg_consolidate_multi", "kg_consolidate_select"]
 
@@ -101,6 +101,21 @@ class Library:
         st = abi.Stats()
         self._check(self.dll.kg_stats_get(self.ctx, C.byref(st)))
         return st
+
+    def candidates_order(self, catalog, cluster, n_nodes, lifetime=None, blocked=None):
+        """-> (node indices in candidate order, costs); catalog may be None."""
+        import numpy as np
+
+        class Inputs(C.Structure):
+            _fields_ = [("lifetime_remaining", C.c_void_p), ("blocked", C.c_void_p), ("n_nodes", C.c_uint32)]
+        lt = None if lifetime is None else np.ascontiguousarray(lifetime, "<f8")
+        bl = None if blocked is None else np.ascontiguousarray(blocked, "u1")
+        inp = Inputs(abi._ptr(lt), abi._ptr(bl), n_nodes)
+        out, costs, n = np.zeros(max(n_nodes, 1), "<i4"), np.zeros(max(n_nodes, 1), "<f8"), C.c_uint32(0)
+        f = self.dll.kg_candidates_order
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        self._check(f(self.ctx, catalog, cluster, C.byref(inp), out.ctypes.data, costs.ctypes.data, n_nodes, C.byref(n)))
+        return out[:n.value].tolist(), costs[:n.value].tolist()
 
     def catalog_size(self, catalog):
         n, g = C.c_uint32(0), C.c_uint64(0)

@@ -68,6 +68,20 @@ def consolidate_records(catalogs, cluster, pending, nodepools, cands, multi):
     return st, recs[:k.value], ms.value
 
 
+def candidates_order(catalog, cluster, n_nodes, lifetime=None, blocked=None):
+    """-> (status, node indices in candidate order, costs)"""
+    import numpy as np
+    f = lib().ko_candidates_order
+    f.restype = C.c_int32
+    f.argtypes = [C.c_void_p] * 6 + [C.c_uint32, C.c_void_p]
+    out, costs, n = np.zeros(max(n_nodes, 1), "<i4"), np.zeros(max(n_nodes, 1), "<f8"), C.c_uint32(0)
+    lt = None if lifetime is None else np.ascontiguousarray(lifetime, "<f8")
+    bl = None if blocked is None else np.ascontiguousarray(blocked, "u1")
+    st = f(C.addressof(catalog.desc) if catalog is not None else None, C.addressof(cluster.desc), abi._ptr(lt), abi._ptr(bl), out.ctypes.data,
+           costs.ctypes.data, n_nodes, C.byref(n))
+    return st, out[:n.value].tolist(), costs[:n.value].tolist()
+
+
 def consolidate_decide(catalogs, cluster, pending, nodepools, cands, multi, cap_types=1024):
     """The reference's sequential selection -> (status, decision dict)."""
     arr = (C.c_void_p * len(catalogs))(*[C.addressof(c.desc) for c in catalogs])

@@ -1520,6 +1520,49 @@ int32_t ko_solve(const kg_catalog_desc* const* catalogs, uint32_t n_catalogs, co
   }
 }
 
+// Candidate eligibility, disruption cost and order (designs/consolidation.md:25-42; disruption.md:17-19), straight from
+// the descriptors: cost = sum over the node's pods of clamp(1 + deletionCost/2^27 + priority/2^25, -10, 10) *
+// lifetimeRemaining; eligible = initialised, managed (nodepool label), not deleting, instance type known to the catalog,
+// not blocked; order = ascending cost, ties keep node order.
+int32_t ko_candidates_order(const kg_catalog_desc* catalog, const kg_cluster_desc* cluster, const double* lifetime, const uint8_t* blocked,
+                            int32_t* out_nodes, double* out_costs, uint32_t cap, uint32_t* n_out) {
+  try {
+    const uint32_t N = cluster->n_nodes;
+    vector<double> cost(N, 0.0);
+    for (uint32_t i = 0; i < cluster->pods.n_pods; ++i) {
+      const kg_pod& p = cluster->pods.pods[i];
+      if (p.node < 0 || (uint32_t)p.node >= N) continue;
+      double c = 1.0 + p.deletion_cost / 134217728.0 + p.priority / 33554432.0;
+      if (c < -10.0) c = -10.0;
+      if (c > 10.0) c = 10.0;
+      cost[p.node] += c;
+    }
+    std::set<string> typeNames;
+    if (catalog) for (uint32_t t = 0; t < catalog->n_types; ++t) typeNames.insert(string(kgdesc::str(catalog->pools.strings, catalog->types[t].name)));
+    vector<int32_t> order;
+    for (uint32_t i = 0; i < N; ++i) {
+      const kg_node& n = cluster->nodes[i];
+      if (lifetime) cost[i] *= lifetime[i];
+      if (!n.initialized || !n.managed || n.deleting || (blocked && blocked[i])) continue;
+      bool pool = false, type = false;
+      for (auto& l : kgdesc::span(cluster->pods.pools.labels, cluster->pods.pools.n_labels, n.labels, "node labels")) {
+        const auto k = kgdesc::str(cluster->pods.pools.strings, l.key);
+        if (k == "karpenter.sh/nodepool") pool = true;
+        if (k == "node.kubernetes.io/instance-type") type = !catalog || typeNames.count(string(kgdesc::str(cluster->pods.pools.strings, l.value)));
+      }
+      if (pool && type) order.push_back((int32_t)i);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cost[a] < cost[b]; });
+    *n_out = (uint32_t)order.size();
+    if (order.size() > cap) return KG_ENOMEM;
+    for (size_t k = 0; k < order.size(); ++k) { out_nodes[k] = order[k]; if (out_costs) out_costs[k] = cost[order[k]]; }
+    return KG_OK;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "ko_candidates_order: %s\n", e.what());
+    return KG_EINVAL;
+  }
+}
+
 // computeConsolidation for every unit of this shard (same records as kg_consolidate_single / _multi)
 int32_t ko_consolidate_records(const kg_catalog_desc* const* catalogs, uint32_t n_catalogs, const kg_cluster_desc* cluster,
                                const kg_pods_desc* pending, const kg_nodepools_desc* nodepools, const kg_candidates_desc* cands, int32_t multi,

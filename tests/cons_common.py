@@ -87,3 +87,47 @@ def check_consolidation(L, name, n, spot_to_spot, n_shards=3):
         L.dll.kg_cluster_free(hcl)
         L.dll.kg_catalog_free(hcat)
     return seen
+
+
+def check_candidates_order(L):
+    """kg_candidates_order against the oracle's restatement and, where every node is eligible, the
+    Python statement of the cost formula: eligibility filters, lifetimeRemaining weights, blocked nodes, stable ties."""
+    zones, types = catalog776()
+    nodes, bound = wl.dense_cluster(300, 5, types, zones)
+    r = wl.SplitMix64(3)
+    for p in bound:
+        p["deletion_cost"] = int(r.below(2000)) * 100000 - 100000000
+    for i, nd in enumerate(nodes):
+        if i % 11 == 0:
+            nd["initialized"] = False
+        if i % 13 == 0:
+            nd["deleting"] = True
+        if i % 17 == 0:
+            nd["managed"] = False
+        if i % 19 == 0:
+            nd["labels"]["node.kubernetes.io/instance-type"] = "x9.mystery"
+        if i % 23 == 0:
+            del nd["labels"][wl.L_NODEPOOL]
+    cat, cl = abi.build_catalog(types), abi.build_cluster(nodes, bound)
+    hcat, hcl = L.catalog_upload(cat), L.cluster_upload(cl)
+    try:
+        lifetime = np.array([1.0 - (i % 7) / 10.0 for i in range(len(nodes))])
+        blocked = np.array([1 if i % 29 == 0 else 0 for i in range(len(nodes))], "u1")
+        sizes = []
+        for lt, bl, with_cat in ((None, None, True), (lifetime, blocked, True), (lifetime, None, False)):
+            st, o_nodes, o_costs = loader.candidates_order(cat if with_cat else None, cl, len(nodes), lt, bl)
+            assert st == 0
+            g_nodes, g_costs = L.candidates_order(hcat if with_cat else None, hcl, len(nodes), lt, bl)
+            assert o_nodes == g_nodes and o_costs == g_costs
+            assert g_costs == sorted(g_costs)
+            sizes.append(len(g_nodes))
+        assert sizes[0] > sizes[1] and sizes[2] > sizes[1] and sizes[0] < len(nodes)
+        nodes2, bound2 = wl.dense_cluster(200, 6, types, zones)
+        hcl2 = L.cluster_upload(abi.build_cluster(nodes2, bound2))
+        try:
+            assert L.candidates_order(hcat, hcl2, len(nodes2))[0] == wl.disruption_order(nodes2, bound2)
+        finally:
+            L.dll.kg_cluster_free(hcl2)
+    finally:
+        L.dll.kg_cluster_free(hcl)
+        L.dll.kg_catalog_free(hcat)

@@ -23,3 +23,8 @@ def test_consolidation(L, name, n, s2s):
     seen = check_consolidation(L, name, n, s2s)
     if name == "dense":
         assert seen == {0, 1, 2}  # no-op, delete and replace all occur
+
+
+def test_candidates_order(L):
+    from tests.cons_common import check_candidates_order
+    check_candidates_order(L)

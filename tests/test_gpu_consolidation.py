@@ -19,3 +19,8 @@ def L():
                                          ("uninitialized", 90, False), ("dense", 400, True), ("topology", 150, True), ("topology", 400, False), ("minvalues_loose", 120, True), ("minvalues_tight", 150, False), ("minvalues_trunc_pending", 120, True)])
 def test_consolidation(L, name, n, s2s):
     check_consolidation(L, name, n, s2s)
+
+
+def test_candidates_order(L):
+    from tests.cons_common import check_candidates_order
+    check_candidates_order(L)
