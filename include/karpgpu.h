@@ -447,6 +447,15 @@ int32_t kg_consolidate_multi(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t 
 /* first-wins (single) / binary-search replay (multi) over records gathered from all shards. */
 int32_t kg_consolidate_select(kg_ctx* ctx, kg_catalog* catalog, int32_t multi, const kg_candidate_record* records, uint32_t n_records,
                               uint32_t n_candidates, kg_decision* out);
+/* Validation re-simulation (Appendix A.9 "wait 15 s, recompute candidates, re-simulate, require the
+ * same outcome"): the caller uploads a FRESH cluster snapshot and passes the command it is about to execute -- its
+ * candidate nodes (indices into the fresh snapshot, at most 100), KG_DECISION_DELETE / _REPLACE and, for a replace, the
+ * instance types it would launch.  *valid = 1 when every rescheduled pod still schedules and the simulation ends in the
+ * same kind of outcome: no new NodeClaim for a delete; exactly one for a replace, whose (truncated) options still
+ * contain every type of the command. */
+int32_t kg_consolidate_validate(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, kg_cluster* cluster, const kg_pods_desc* pending,
+                                const kg_nodepools_desc* nodepools, const int32_t* candidates, uint32_t n_candidates, int32_t decision,
+                                const uint32_t* type_ids, uint32_t n_types, uint8_t* valid, double* device_ms);
 
 #ifdef __cplusplus
 }

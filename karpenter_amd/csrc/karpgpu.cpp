@@ -1681,9 +1681,16 @@ void remove_by_price(const kg_catalog* cat, Replacement* r, double max_price, in
 
 }  // namespace
 
+// what a validation re-simulation reports (kg_consolidate_validate)
+struct ValidateOut {
+  bool all_scheduled = false;
+  uint32_t n_claims = 0;          // new NodeClaims left after Results.TruncateInstanceTypes
+  std::vector<uint32_t> types;    // options of the one NodeClaim, truncated
+};
+
 static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, kg_cluster* cluster, const kg_pods_desc* pending,
                                 const kg_nodepools_desc* nodepools, const kg_candidates_desc* cands, bool multi, kg_candidate_record* records,
-                                uint32_t cap_records, uint32_t* n_records, double* device_ms) {
+                                uint32_t cap_records, uint32_t* n_records, double* device_ms, ValidateOut* vout = nullptr) {
   if (!ctx || !catalogs || n_catalogs == 0 || !cluster || !nodepools || !cands || !n_records || (!records && cap_records)) return KG_EINVAL;
   std::lock_guard<std::mutex> lk(ctx->mu);
   KG_GUARD_BEGIN
@@ -1734,7 +1741,8 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   struct Unit { uint32_t id; uint32_t pod_lo, pod_hi; bool skip; };
   std::vector<Unit> units;
   const uint32_t lo = multi ? 1 : 0, hi = multi ? n_used : n;
-  for (uint32_t u = lo; u < hi; ++u) {
+  if (vout && n_used > 0) units.push_back(Unit{n_used - 1, n_shared, cand_begin[n_used], false});  // one simulation: every candidate of the command
+  for (uint32_t u = lo; u < hi && !vout; ++u) {
     if ((int)((u - lo) % shards) != cands->shard) continue;
     Unit un{u, multi ? n_shared : cand_begin[u], cand_begin[u + 1], false};
     if (!multi && un.pod_hi == un.pod_lo) un.skip = true;  // no reschedulable pods: emptiness handles the node
@@ -1751,6 +1759,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   for (size_t k = 0; k < units.size(); ++k)
     if (!units[k].skip) { live.push_back((uint32_t)k); cmax = std::max(cmax, (int)(n_shared + units[k].pod_hi - units[k].pod_lo)); }
   if (live.empty()) return KG_OK;
+  if (vout) multi = true;  // (the unit is a prefix: every candidate up to its id is taken out of the cluster)
 
   // ---- compile once; every simulation shares the problem tables
   SolveInputs in{ctx, cat, cluster, nodepools, &U};
@@ -1857,6 +1866,37 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   if (device_ms) *device_ms = ms_total;
   ctx->stats.device_ms_total += ms_total;
 
+  if (vout) {
+    // validation: AllNonPendingPodsScheduled, and the NodeClaims Results.TruncateInstanceTypes leaves
+    const SimResult& sr = results[0];
+    vout->all_scheduled = sr.errors == 0;
+    vout->n_claims = sr.nclaims;
+    if (sr.errors == 0 && sr.nclaims == 1) {
+      uint64_t zmask = allowed1(sr.zone_meta, sr.zone_word);
+      const uint64_t ctmask = allowed1(sr.ct_meta, sr.ct_word), zidm = allowed1(sr.zid_meta, sr.zid_word);
+      const uint8_t* zz = cat->tab.image.bytes.data() + cat->tab.o_zone_zid;
+      if (sr.zid_meta & RM_PRESENT)
+        for (int z = 0; z < 64; ++z) if (zz[z] != 0xFF && !((zidm >> zz[z]) & 1)) zmask &= ~(1ull << z);
+      std::vector<uint32_t> types;
+      for (int w = 0; w < C->TW && w < KG_TWLDS; ++w)
+        for (uint64_t m = sr.mask[w]; m; m &= m - 1) types.push_back((uint32_t)(w * 64 + __builtin_ctzll(m)));
+      order_by_price(cat, &types, zmask, ctmask);
+      std::vector<std::pair<uint32_t, int>> mv;
+      for (auto& q : C->templates[sr.tmpl].reqs.rs) if (q.min_values >= 0) mv.push_back({q.key, q.min_values});
+      if (nodepools->max_instance_types > 0) {
+        std::vector<uint32_t> trunc(types.begin(), types.begin() + std::min<size_t>(types.size(), (size_t)nodepools->max_instance_types));
+        if (!mv.empty() && !satisfies_min_values(cat, trunc, mv)) {
+          // the claim is dropped and its pods fail
+          if (sr.pad) vout->all_scheduled = false;
+          vout->n_claims = 0;
+          trunc.clear();
+        }
+        types.swap(trunc);
+      }
+      vout->types = types;
+    }
+    return KG_OK;
+  }
   // ---- computeConsolidation's decision logic per simulation (prices are float64 catalog data: host side)
   const int spot = V.vals[ctx->kCT].find("spot"), od = V.vals[ctx->kCT].find("on-demand");
   std::unordered_map<std::string, int> type_by_name;
@@ -1994,6 +2034,33 @@ int32_t kg_consolidate_multi(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t 
                              const kg_nodepools_desc* nodepools, const kg_candidates_desc* cands, kg_candidate_record* records,
                              uint32_t cap_records, uint32_t* n_records, double* device_ms) {
   return consolidate_impl(ctx, catalogs, n_catalogs, cluster, pending, nodepools, cands, true, records, cap_records, n_records, device_ms);
+}
+
+// Validation of a consolidation command against a fresh cluster snapshot: one more
+// SimulateScheduling with the command's candidates; valid when every rescheduled pod still schedules and the outcome is
+// the same kind -- no new NodeClaim for a DELETE; exactly one for a REPLACE, whose options still contain every instance
+// type of the command.
+int32_t kg_consolidate_validate(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, kg_cluster* cluster, const kg_pods_desc* pending,
+                                const kg_nodepools_desc* nodepools, const int32_t* candidates, uint32_t n_candidates, int32_t decision,
+                                const uint32_t* type_ids, uint32_t n_types, uint8_t* valid, double* device_ms) {
+  if (!valid || (!candidates && n_candidates) || (!type_ids && n_types)) return KG_EINVAL;
+  *valid = 0;
+  if (n_candidates == 0 || n_candidates > 100 || decision == KG_DECISION_NOOP) return KG_EINVAL;
+  kg_candidates_desc cd{};
+  cd.candidates = candidates; cd.n_candidates = n_candidates; cd.shard = 0; cd.n_shards = 1;
+  kg_candidate_record rec;
+  uint32_t nrec = 0;
+  ValidateOut vo;
+  const int32_t st = consolidate_impl(ctx, catalogs, n_catalogs, cluster, pending, nodepools, &cd, true, &rec, 1, &nrec, device_ms, &vo);
+  if (st != KG_OK) return st;
+  if (!vo.all_scheduled) return KG_OK;
+  if (vo.n_claims == 0) { *valid = decision == KG_DECISION_DELETE; return KG_OK; }
+  if (vo.n_claims > 1 || decision != KG_DECISION_REPLACE) return KG_OK;
+  std::set<uint32_t> have(vo.types.begin(), vo.types.end());
+  bool subset = n_types > 0;
+  for (uint32_t i = 0; i < n_types; ++i) subset = subset && have.count(type_ids[i]) != 0;
+  *valid = subset;
+  return KG_OK;
 }
 
 // SingleNodeConsolidation.ComputeCommand (first candidate in order with a command) / the binary search of

@@ -12,7 +12,7 @@ from . import abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_PATH = os.path.join(_HERE, "libkarpgpu.so")
 
-EXPORTS = ["kg_init", "kg_destroy", "kg_last_error", "kg_stats_get", "kg_catalog_upload", "kg_catalog_build_ec2", "kg_catalog_update_offerings", "kg_candidates_order",
+EXPORTS = ["kg_init", "kg_destroy", "kg_last_error", "kg_stats_get", "kg_catalog_upload", "kg_catalog_build_ec2", "kg_catalog_update_offerings", "kg_candidates_order", "kg_consolidate_validate",
            "kg_catalog_query", "kg_catalog_size", "kg_catalog_free", "kg_cluster_upload", "kg_cluster_free", "kg_solve",
            "kg_truncate", "kg_launch_filter", "kg_consolidate_single", "kg_consolidate_multi", "kg_consolidate_select"]
 
@@ -116,6 +116,18 @@ class Library:
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         self._check(f(self.ctx, catalog, cluster, C.byref(inp), out.ctypes.data, costs.ctypes.data, n_nodes, C.byref(n)))
         return out[:n.value].tolist(), costs[:n.value].tolist()
+
+    def consolidate_validate(self, catalogs, cluster, pending, nodepools, candidates, decision, type_ids):
+        """-> valid (bool)"""
+        import numpy as np
+        arr = (C.c_void_p * len(catalogs))(*catalogs)
+        ca, ta, v, ms = np.array(list(candidates), "<i4"), np.array(list(type_ids), "<u4"), C.c_uint8(0), C.c_double(0)
+        f = self.dll.kg_consolidate_validate
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p,
+                      C.c_uint32, C.c_void_p, C.c_void_p]
+        self._check(f(self.ctx, arr, len(catalogs), cluster, C.addressof(pending.desc), C.addressof(nodepools.desc), ca.ctypes.data, len(ca),
+                      decision, abi._ptr(ta), len(ta), C.byref(v), C.byref(ms)))
+        return bool(v.value)
 
     def catalog_size(self, catalog):
         n, g = C.c_uint32(0), C.c_uint64(0)

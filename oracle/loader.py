@@ -82,6 +82,19 @@ def candidates_order(catalog, cluster, n_nodes, lifetime=None, blocked=None):
     return st, out[:n.value].tolist(), costs[:n.value].tolist()
 
 
+def consolidate_validate(catalogs, cluster, pending, nodepools, candidates, decision, type_ids):
+    """-> (status, valid)"""
+    import numpy as np
+    f = lib().ko_consolidate_validate
+    f.restype = C.c_int32
+    f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p]
+    arr = (C.c_void_p * len(catalogs))(*[C.addressof(c.desc) for c in catalogs])
+    ca, ta, v = np.array(list(candidates), "<i4"), np.array(list(type_ids), "<u4"), C.c_uint8(0)
+    st = f(arr, len(catalogs), C.addressof(cluster.desc), C.addressof(pending.desc), C.addressof(nodepools.desc), ca.ctypes.data, len(ca),
+           decision, abi._ptr(ta), len(ta), C.byref(v))
+    return st, bool(v.value)
+
+
 def consolidate_decide(catalogs, cluster, pending, nodepools, cands, multi, cap_types=1024):
     """The reference's sequential selection -> (status, decision dict)."""
     arr = (C.c_void_p * len(catalogs))(*[C.addressof(c.desc) for c in catalogs])

@@ -1324,7 +1324,12 @@ static bool candidatePrice(Problem& pr, int node, double* price) {
 }
 
 // disruption.SimulateScheduling + consolidation.computeConsolidation for one set of candidate nodes
-static Outcome computeConsolidation(Problem& pr, const vector<int>& cands, bool spotToSpotEnabled, uint64_t* sims) {
+struct SimRaw {  // what validation needs of SimulateScheduling
+  bool allScheduled = false;
+  int nClaims = 0;
+  vector<int> types;  // options of the one NodeClaim after TruncateInstanceTypes
+};
+static Outcome computeConsolidation(Problem& pr, const vector<int>& cands, bool spotToSpotEnabled, uint64_t* sims, SimRaw* raw = nullptr) {
   SchedCtx& C = pr.C;
   Outcome out;
   (*sims)++;
@@ -1352,6 +1357,11 @@ static Outcome computeConsolidation(Problem& pr, const vector<int>& cands, bool 
   for (auto& kv : errs) if (nonPending.count(origin[kv.first])) return out;  // !AllNonPendingPodsScheduled
   vector<NodeClaim*> claims;
   for (size_t i = 0; i < s->newNodeClaims.size(); ++i) if (!truncFailed[i]) claims.push_back(s->newNodeClaims[i].get());
+  if (raw) {
+    raw->allScheduled = true;
+    raw->nClaims = (int)claims.size();
+    if (claims.size() == 1) for (auto* it : claims[0]->options) raw->types.push_back(it->index);
+  }
   if (claims.empty()) { out.decision = KG_DECISION_DELETE; return out; }
   if (claims.size() != 1) return out;
   double price = 0;
@@ -1586,6 +1596,33 @@ int32_t ko_consolidate_records(const kg_catalog_desc* const* catalogs, uint32_t 
     return k > cap_records ? KG_ENOMEM : KG_OK;
   } catch (const std::exception& e) {
     fprintf(stderr, "ko_consolidate_records: %s\n", e.what());
+    return KG_EINVAL;
+  }
+}
+
+// Validation (disruption validation: re-simulate the command against the current cluster, require the same outcome --
+// SURVEY.md Appendix A.9): every rescheduled pod schedules; a delete creates no NodeClaim; a replace creates exactly one
+// whose options still contain every instance type of the command.
+int32_t ko_consolidate_validate(const kg_catalog_desc* const* catalogs, uint32_t n_catalogs, const kg_cluster_desc* cluster,
+                                const kg_pods_desc* pending, const kg_nodepools_desc* nodepools, const int32_t* candidates, uint32_t n_candidates,
+                                int32_t decision, const uint32_t* type_ids, uint32_t n_types, uint8_t* valid) {
+  try {
+    *valid = 0;
+    auto pr = buildProblem(catalogs, n_catalogs, cluster, pending, nodepools);
+    vector<int> cands(candidates, candidates + n_candidates);
+    uint64_t sims = 0;
+    SimRaw raw;
+    computeConsolidation(*pr, cands, false, &sims, &raw);
+    if (!raw.allScheduled) return KG_OK;
+    if (raw.nClaims == 0) { *valid = decision == KG_DECISION_DELETE; return KG_OK; }
+    if (raw.nClaims > 1 || decision != KG_DECISION_REPLACE) return KG_OK;
+    std::set<int> have(raw.types.begin(), raw.types.end());
+    bool subset = n_types > 0;
+    for (uint32_t i = 0; i < n_types; ++i) subset = subset && have.count((int)type_ids[i]);
+    *valid = subset;
+    return KG_OK;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "ko_consolidate_validate: %s\n", e.what());
     return KG_EINVAL;
   }
 }

@@ -131,3 +131,56 @@ def check_candidates_order(L):
     finally:
         L.dll.kg_cluster_free(hcl)
         L.dll.kg_catalog_free(hcat)
+
+
+def check_validate(L, n=90):
+    """kg_consolidate_validate against the oracle: commands computed on a cluster are re-checked on
+    the same snapshot (valid), on a snapshot where the other nodes have filled up (deletes turn invalid), and with the wrong
+    kind of command; single- and multi-candidate commands."""
+    types, nodes, bound, pending = cluster("dense", n)
+    order = wl.disruption_order(nodes, bound)
+    cat = abi.build_catalog(types)
+    pend, nps = abi.build_pods(pending), abi.build_nodepools([wl.default_nodepool()], wl.WELL_KNOWN_LABELS)
+    cl = abi.build_cluster(nodes, bound)
+    # the later snapshot: every node but the first 5 candidates has lost its free cpu
+    nodes_b = [dict(nd, available=dict(nd["available"])) for nd in nodes]
+    for i, nd in enumerate(nodes_b):
+        if i not in order[:5]:
+            nd["available"]["cpu"] = 0
+    cl_b = abi.build_cluster(nodes_b, bound)
+    hcat, hcl, hcl_b = L.catalog_upload(cat), L.cluster_upload(cl), L.cluster_upload(cl_b)
+    try:
+        recs, _ = L.consolidate_records([hcat], hcl, pend, nps, abi.build_candidates(order[:40], spot_to_spot=True), False)
+        outcomes = set()
+        n_cmd = 0
+        for r in recs:
+            dec = int(r["decision"])
+            if dec == 0:
+                continue
+            n_cmd += 1
+            cands = [order[int(r["candidate"])]]
+            tids = [w * 64 + b for w in range(13) for b in range(64) if (int(r["type_mask"][w]) >> b) & 1]
+            for snap, hsnap in ((cl, hcl), (cl_b, hcl_b)):
+                for d, t in ((dec, tids), (3 - dec, tids if dec == 1 else []), (2, [0, 1, 2])):
+                    if d == 2 and not t:
+                        continue
+                    st, vo = loader.consolidate_validate([cat], snap, pend, nps, cands, d, t if d == 2 else [])
+                    assert st == 0
+                    vg = L.consolidate_validate([hcat], hsnap, pend, nps, cands, d, t if d == 2 else [])
+                    assert vo == vg, (cands, d, snap is cl)
+                    outcomes.add((snap is cl, d == dec, vg))
+            assert L.consolidate_validate([hcat], hcl, pend, nps, cands, dec, tids if dec == 2 else [])  # unchanged snapshot: still valid
+        assert n_cmd >= 5
+        assert (True, True, True) in outcomes and (False, True, False) in outcomes and (True, False, False) in outcomes
+        # a multi-node command
+        dm = L.consolidate_select(hcat, L.consolidate_records([hcat], hcl, pend, nps, abi.build_candidates(order), True)[0], len(order), True)
+        if dm["decision"] != 0:
+            cands = order[:dm["n_candidates"]]
+            for snap, hsnap in ((cl, hcl), (cl_b, hcl_b)):
+                st, vo = loader.consolidate_validate([cat], snap, pend, nps, cands, dm["decision"], dm["types"])
+                assert st == 0 and vo == L.consolidate_validate([hcat], hsnap, pend, nps, cands, dm["decision"], dm["types"])
+            assert L.consolidate_validate([hcat], hcl, pend, nps, cands, dm["decision"], dm["types"])
+    finally:
+        L.dll.kg_cluster_free(hcl)
+        L.dll.kg_cluster_free(hcl_b)
+        L.dll.kg_catalog_free(hcat)

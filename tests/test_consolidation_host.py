@@ -28,3 +28,8 @@ def test_consolidation(L, name, n, s2s):
 def test_candidates_order(L):
     from tests.cons_common import check_candidates_order
     check_candidates_order(L)
+
+
+def test_validate_command(L):
+    from tests.cons_common import check_validate
+    check_validate(L)
