@@ -1,5 +1,6 @@
 import sys
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from karpenter_amd import lib, workloads as wl
 from tests.helpers import Problem, catalog776, families
 L = lib.Library()
