@@ -7,6 +7,7 @@
 // the Preferences.Relax chain of each pod as a list of precompiled variants; topology groups with
 // their initial domain counts.
 #pragma once
+#include <array>
 #include <set>
 
 #include "ctx.hpp"
@@ -36,6 +37,7 @@ struct PodClass {
   std::vector<PSpread> spreads;
   std::vector<PTerm> aff_req, aff_pref, anti_req, anti_pref;
   bool host_ports = false;
+  std::vector<std::array<int, 3>> ports;  // (ip label id or -1 = 0.0.0.0, port, protocol)
 };
 
 struct PodRef {

@@ -106,6 +106,16 @@ __global__ void __launch_bounds__(NT) k_solve(DevProblem Pin, const SimState* si
   if ((P.stats & 2) && threadIdx.x == 0) { S.counters[24] = clock64() - c0; S.counters[25] = wall_clock64() - w0; }
 }
 
+// k_simulate: the same solve loop, one workgroup per consolidation simulation (a kernel of its own so that profiles keep
+// the one persistent Solve and the batches of simulations apart)
+template <int NT>
+__global__ void __launch_bounds__(NT) k_simulate(DevProblem Pin, const SimState* sims, const uint32_t* nqueue) {
+  __shared__ Shared sh;
+  const DevProblem& P = Pin;
+  const SimState S = sims[blockIdx.x];
+  solve_block<NT>(P, S, sh, nqueue[blockIdx.x]);
+}
+
 // k_sim_init: one workgroup per simulation copies the pristine state image into its slot and applies the patches
 __global__ void __launch_bounds__(256) k_sim_init(DevProblem P, SimBatch B) {
   sim_init_copy(B, blockIdx.x, threadIdx.x, blockDim.x);
@@ -168,8 +178,15 @@ void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms) {
   *ms = t.stop();
 }
 
-void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int block, float* ms) {
+void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int block, float* ms, bool batch) {
   Timer t;
+  if (batch) {
+    if (block >= 512) hipLaunchKernelGGL((k_simulate<512>), dim3(nsims), dim3(512), 0, 0, P, sims, nqueue);
+    else hipLaunchKernelGGL((k_simulate<256>), dim3(nsims), dim3(256), 0, 0, P, sims, nqueue);
+    ck(hipGetLastError(), "simulate launch");
+    *ms = t.stop();
+    return;
+  }
   if (block >= 1024) hipLaunchKernelGGL((k_solve<1024>), dim3(nsims), dim3(1024), 0, 0, P, sims, nqueue);
   else if (block >= 512) hipLaunchKernelGGL((k_solve<512>), dim3(nsims), dim3(512), 0, 0, P, sims, nqueue);
   else hipLaunchKernelGGL((k_solve<256>), dim3(nsims), dim3(256), 0, 0, P, sims, nqueue);

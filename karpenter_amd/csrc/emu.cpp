@@ -29,7 +29,7 @@ void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms) {
   *ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
-void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int block, float* ms) {
+void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int block, float* ms, bool) {
   auto t0 = std::chrono::steady_clock::now();
   for (int i = 0; i < nsims; ++i) {
     static Shared sh;

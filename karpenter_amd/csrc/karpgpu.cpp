@@ -127,6 +127,7 @@ void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out, bool add_po
       }
     }
     sg.u32(q.host_ports.count);
+    for (auto& h : kgdesc::span(d->host_ports, d->n_host_ports, q.host_ports, "host port range")) { sg.u32(h.ip); sg.u32((uint32_t)h.port); sg.u32(h.protocol); }
     uint32_t cls;
     auto it = by_sig.find(sg.s);
     if (it != by_sig.end()) {
@@ -153,6 +154,8 @@ void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out, bool add_po
       c.anti_req = parse_terms(ctx, d, q.anti_affinity_required);
       c.anti_pref = parse_terms(ctx, d, q.anti_affinity_preferred);
       c.host_ports = q.host_ports.count != 0;
+      for (auto& h : kgdesc::span(d->host_ports, d->n_host_ports, q.host_ports, "host port range"))
+        c.ports.push_back({h.ip == KG_NONE ? -1 : (int)ctx->lab.id(kgdesc::str(p.strings, h.ip)), h.port, (int)h.protocol});
       cls = (uint32_t)out->classes.size();
       out->classes.push_back(std::move(c));
       by_sig.emplace(sg.s, cls);
@@ -283,6 +286,7 @@ struct Compiled {
   // simulations that reschedule it): gcount index g * 64 + d, or 0x80000000 | hcount index
   std::vector<std::vector<uint32_t>> contrib;
   std::vector<uint64_t> gdom_univ;   // [G] domains registered from the NodePools / instance types alone
+  size_t o_nports, o_cports;
   size_t o_nreq, o_creq, o_chead, o_chstamp, o_cmask, o_cbits, o_cmeta, o_cnpods, o_ctmpl, o_order, o_remaining, o_gcount, o_gdom, o_gpos, o_hcount, o_hpos, o_queue,
       o_podkind, o_excl, o_podindex, o_podreason, o_scratch, o_ordg, o_header, o_counters, o_nqueue;
   ~Compiled() {
@@ -398,7 +402,6 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   std::vector<std::vector<RelaxState>> chains(NC);
   for (size_t ci = 0; ci < NC; ++ci) {
     const PodClass& c = PP.classes[ci];
-    if (c.host_ports) throw Unsupported("host ports are not handled on the device path");
     RelaxState st{c.required, c.preferred, c.tols, c.spreads, c.aff_pref, c.anti_pref};
     chains[ci].push_back(st);
     while (relax_step(st, tolerate_pns, ctx)) {
@@ -703,6 +706,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   // ---- lists, variants
   std::vector<ListEntry> lists;
   std::vector<Variant> variants;
+  std::vector<uint32_t> variant_class;  // variant -> pod class (host ports are a property of the class)
   std::vector<uint32_t> class_variant0(NC);
   auto poddom = [&](const HReqs& strict, uint32_t key) {
     const HReq* q = strict.find(key);
@@ -752,6 +756,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
       v.host_claim_ok = rs_host_claim_ok[vt.rs];
       next = (int32_t)variants.size();
       variants.push_back(v);
+      variant_class.push_back((uint32_t)ci);
     }
     class_variant0[ci] = (uint32_t)next;
   }
@@ -972,6 +977,38 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     for (size_t i = 0; i < idx.size() && idx[i] < 64; ++i) vrank[sp * 64 + idx[i]] = (uint16_t)i;
   }
 
+  // ---- host ports (scheduling.HostPortUsage): the distinct (ip, port, protocol) entries of this solve's pods form a
+  // vocabulary of <= 64 ids; a node / NodeClaim holds the ids reserved on it in one word, a pod class the ids it reserves
+  // and the ids that conflict with one of them (same port and protocol, equal ips or either one 0.0.0.0)
+  std::vector<std::array<int, 3>> port_vocab;
+  auto port_id = [&](const std::array<int, 3>& h) {
+    for (size_t i = 0; i < port_vocab.size(); ++i) if (port_vocab[i] == h) return (int)i;
+    if (port_vocab.size() >= 64) throw Unsupported("more than 64 distinct host ports in one solve");
+    port_vocab.push_back(h);
+    return (int)port_vocab.size() - 1;
+  };
+  for (auto& c : PP.classes) for (auto& h : c.ports) port_id(h);
+  if (cl) for (auto& c : cl->bound.classes) for (auto& h : c.ports) port_id(h);
+  auto port_use = [&](const PodClass& c) { uint64_t m = 0; for (auto& h : c.ports) m |= 1ull << port_id(h); return m; };
+  auto port_conf = [&](const PodClass& c) {
+    uint64_t m = 0;
+    for (auto& h : c.ports)
+      for (size_t i = 0; i < port_vocab.size(); ++i) {
+        const auto& o = port_vocab[i];
+        if (o[1] == h[1] && o[2] == h[2] && (o[0] == h[0] || o[0] == -1 || h[0] == -1)) m |= 1ull << i;
+      }
+    return m;
+  };
+  std::vector<uint64_t> nports0(std::max(N, 1), 0);
+  if (cl && !port_vocab.empty()) {
+    std::vector<int> pos_of(cl->nodes.size(), -1);
+    for (int n = 0; n < N; ++n) pos_of[C.node_order[n]] = n;
+    for (auto& bp : cl->bound.pods) {
+      if (bp.node < 0 || (size_t)bp.node >= cl->nodes.size() || pos_of[bp.node] < 0) continue;
+      nports0[pos_of[bp.node]] |= port_use(cl->bound.classes[bp.cls]);
+    }
+  }
+
   // ---- one precompiled record per pod variant (what NodeClaim.Add / ExistingNode.Add need of the pod)
   const int NV = (int)variants.size();
   std::vector<VariantCtx> vctx(std::max(NV, 1));
@@ -979,6 +1016,8 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     VariantCtx& vc = vctx[vi];
     std::memset(&vc, 0, sizeof vc);
     vc.v = variants[vi];
+    vc.hp_use = port_use(PP.classes[variant_class[vi]]);
+    vc.hp_conf = port_conf(PP.classes[variant_class[vi]]);
     const uint32_t rs = vc.v.rs;
     vc.ne = rs_off[rs + 1] - rs_off[rs];
     uint32_t used = 0;
@@ -1043,6 +1082,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   while (TWP < TW) TWP *= 2;
   if (TWP > 256) throw Unsupported("more than 16384 instance types");
   D.tmpl_minv_mask = tmpl_minv_mask;
+  D.has_ports = port_vocab.empty() ? 0 : 1;
   D.TWP = TWP; D.NV = NV; D.stats = (stats ? 1 : 0) | (ctx->collect_timers ? 2 : 0);
   for (int r = 0; r < R; ++r) {
     const uint32_t g = C.act_res[r];
@@ -1086,6 +1126,8 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   std::vector<uint32_t> header(16, 0), nqueue{(uint32_t)P};
   std::vector<uint64_t> counters(64, 0);
   C.o_nreq = SA.add(nreq0);
+  C.o_nports = SA.add(nports0);
+  C.o_cports = SA.reserve((size_t)Cmax * 8);
   C.o_creq = SA.reserve((size_t)std::max(R, 1) * Cmax * 8);
   C.o_chead = SA.reserve((size_t)std::max(R, 1) * Cmax * 8);
   C.o_chstamp = SA.reserve((size_t)Cmax * 4);
@@ -1133,6 +1175,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
 static SimState sim_at(const Compiled& C, uint8_t* base) {
   auto sptr = [&](size_t off) { return base + off; };
   SimState St{};
+  St.nports = (uint64_t*)sptr(C.o_nports); St.c_ports = (uint64_t*)sptr(C.o_cports);
   St.nreq = (int64_t*)sptr(C.o_nreq); St.c_req = (int64_t*)sptr(C.o_creq); St.c_head = (int64_t*)sptr(C.o_chead); St.c_hstamp = (uint32_t*)sptr(C.o_chstamp); St.c_mask = (uint64_t*)sptr(C.o_cmask); St.c_bits = (uint64_t*)sptr(C.o_cbits);
   St.c_meta = (uint32_t*)sptr(C.o_cmeta); St.c_npods = (uint32_t*)sptr(C.o_cnpods); St.c_tmpl = (uint16_t*)sptr(C.o_ctmpl); St.c_stamp = (uint32_t*)sptr(C.o_order);
   St.remaining = (int64_t*)sptr(C.o_remaining); St.gcount = (int32_t*)sptr(C.o_gcount); St.gdom = (uint64_t*)sptr(C.o_gdom); St.gpos = (uint64_t*)sptr(C.o_gpos);
@@ -1856,7 +1899,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
     B.pod_nonpending = (const uint8_t*)pp(o_np); B.node_uninit = (const uint64_t*)pp(o_un); B.nsims = (int)nb;
     float ms_i = 0, ms_s = 0, ms_g = 0;
     hal::launch_sim_init(C->dp, B, &ms_i);
-    hal::launch_solve(C->dp, (const SimState*)pp(o_sims), (int)nb, B.nqueue, ctx->sim_block_threads, &ms_s);
+    hal::launch_solve(C->dp, (const SimState*)pp(o_sims), (int)nb, B.nqueue, ctx->sim_block_threads, &ms_s, true);
     hal::launch_sim_gather(C->dp, B, (const SimState*)pp(o_sims), &ms_g);
     hal::d2h(results.data() + b0, pp(o_res), nb * sizeof(SimResult));
     ms_total += ms_i + ms_s + ms_g;

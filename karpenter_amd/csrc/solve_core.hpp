@@ -107,6 +107,7 @@ struct ListX {
 struct VariantCtx {
   Variant v;
   uint32_t ne, nlist;
+  uint64_t hp_use, hp_conf;  // host ports the pod reserves / port ids that conflict with one of them (scheduling.HostPortUsage)
   PodEntry ent[KG_MAXE];
   ListX lst[KG_MAXLIST];
   uint64_t ebits[KG_EBITS];
@@ -119,6 +120,7 @@ struct DevProblem {
   int slot_zone, slot_ct, slot_zid;  // special indices (sp) or -1
   uint32_t well_known_slots;         // bit per active slot
   uint32_t stats;                    // 1 = maintain the reference-visit counters (exact, slower)
+  uint32_t has_ports;                // some pod of this solve (pending or bound) declares a host port
   unsigned long long tmpl_minv_mask;  // bit per template: its requirements carry minValues
   // active resources -> rows of the catalog's per-resource tables
   // (kept behind a pointer: an array inside this by-value struct would push the whole struct into scratch memory)
@@ -187,6 +189,8 @@ struct DevProblem {
 // Mutable state of ONE simulation (device pointers into that simulation's arena).
 struct SimState {
   KG_GLOBAL int64_t* nreq;      // [R][N]
+  KG_GLOBAL uint64_t* nports;   // [N] host-port ids reserved on the node (bit per entry of the solve's port vocabulary)
+  KG_GLOBAL uint64_t* c_ports;  // [Cmax] ... on the NodeClaim
   KG_GLOBAL int64_t* c_req;     // [R][Cmax]
   KG_GLOBAL int64_t* c_head;    // [R][Cmax] upper bound of what the claim can still take: max allocatable over its options - c_req
   KG_GLOBAL uint64_t* c_mask;   // [TW][Cmax]
@@ -745,6 +749,7 @@ KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, u
   const uint32_t wi = n >> 6, bi = n & 63;
   if ((S.excl[wi] >> bi) & 1) return false;  // a candidate of this simulation: not a state node
   if (!((P.ntol[(size_t)v.tolset * P.NW + wi] >> bi) & 1)) { *reason |= 1; return false; }
+  if (P.has_ports && (S.nports[n] & sh.pc.vc.hp_conf)) { *reason |= 2; return false; }  // HostPortUsage.Conflicts
   // resources first (cheap reject), as upstream does
   for (int r = 0; r < P.R; ++r) {
     if (sh.pc.preq[r] != 0 && S.nreq[(size_t)r * P.N + n] + sh.pc.preq[r] > P.navail[(size_t)r * P.N + n]) { *reason |= 64; return false; }
@@ -766,6 +771,7 @@ KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, u
   }
   if (COMMIT) {
     for (int r = 0; r < P.R; ++r) if (sh.pc.preq[r] != 0) S.nreq[(size_t)r * P.N + n] += sh.pc.preq[r];
+    if (P.has_ports) S.nports[n] |= sh.pc.vc.hp_use;
     for (uint32_t li = 0; li < v.record_cnt; ++li) {
       const ListEntry le = P.lists[v.record_off + li];
       const Group g = P.groups[le.g];
@@ -1016,6 +1022,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
                 for (int w = 0; w < P.TW; ++w) any |= S.c_mask[(size_t)w * P.Cmax + c] & pm[w];
               }
               ok = ((P.tol_tmpl[sh.pc.vc.v.tolset] >> tm) & 1) && sh.pc.vc.v.host_claim_ok && any != 0;
+              if (P.has_ports) ok = ok && !(S.c_ports[c] & sh.pc.vc.hp_conf);
 #pragma unroll
               for (int r = 0; r < KG_MAXR; ++r) ok = ok && (!((need >> r) & 1) || hd[r] >= sh.pc.preq[r]);
             }
@@ -1137,6 +1144,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
                 R.npods = (uint32_t)(oe >> 32); R.stamp = S.c_stamp[c];
                 R.c = c; R.tmpl = tm; R.reason = 0; R.pos = pos; R.tv = 0; R.ent_changed = 0; R.ent_dne_ok = 0; R.sp_changed = 0; R.thr_use = 0;
                 R.ok = ((P.tol_tmpl[sh.pc.vc.v.tolset] >> tm) & 1) && sh.pc.vc.v.host_claim_ok;
+                if (P.has_ports && (S.c_ports[c] & sh.pc.vc.hp_conf)) { R.ok = 0; R.reason = 2; }
               }
             }
             KG_ST(5);
@@ -1298,6 +1306,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
         if (tid == NT / 2) {
           if (fr) { S.c_npods[c] = 1; S.c_tmpl[c] = (uint16_t)R.tmpl; S.c_hstamp[c] = seq + 1; }
           else S.c_npods[c] = wnp + 1;
+          if (P.has_ports) S.c_ports[c] = (fr ? 0ull : S.c_ports[c]) | sh.pc.vc.hp_use;
           S.c_stamp[c] = seq + 1;
           S.pod_kind[pod_row(S, pod)] = 2;
           S.pod_index[pod_row(S, pod)] = (int32_t)c;

@@ -41,6 +41,12 @@ def cluster(name, n):
             else:
                 p["affinity_required"] = [{"key": wl.L_ZONE, "selector": sel}]
         return types, nodes, bound, []
+    if name == "host_ports":
+        # a third of the bound pods hold host ports: a candidate's pods cannot move to a node (or share a replacement)
+        # where a conflicting port is taken
+        from tests.helpers import _with_host_ports
+        nodes, bound = wl.dense_cluster(n, 19, types, zones, lo=0.4, hi=0.9)
+        return types, nodes, _with_host_ports(bound, 8), []
     raise KeyError(name)
 
 

@@ -56,6 +56,21 @@ def full_size_problem(name):
     raise KeyError(name)
 
 
+def _with_host_ports(pods, seed, every=3):
+    """Gives every `every`-th pod one or two host ports out of a small set (wildcard and specific ips, tcp / udp), so
+    that conflicts (same port + protocol, equal ips or either 0.0.0.0) decide placements."""
+    r = wl.SplitMix64(seed)
+    ips = [None, "10.0.0.1", "10.0.0.2"]
+    for i, p in enumerate(pods):
+        if i % every:
+            continue
+        hp = [(ips[r.below(3)], 8000 + r.below(4), 6 if r.below(4) else 17)]
+        if r.below(3) == 0:
+            hp.append((ips[r.below(3)], 9000 + r.below(2), 6))
+        p["host_ports"] = hp
+    return pods
+
+
 class Problem:
     """One scheduling problem in descriptor form, usable by both the oracle and the library."""
 
@@ -116,6 +131,15 @@ def scenario(name):
         n_nodes, n_pods = (100, 1500) if name == "c5_small" else (600, 12000)
         nodes, bound = wl.existing_cluster(n_nodes, 13, t6, z6, nodepool="np-a")
         return Problem(t6, wl.mixed_pods(n_pods, 99, z6, families(t6)), c5_nodepools(), nodes=nodes, bound=bound)
+    if name == "host_ports":
+        # host ports on a third of the pods: HostPortUsage conflicts split pods over NodeClaims that resources would share
+        return Problem(types, _with_host_ports(wl.mixed_pods(600, 21, zones, families(types)), 5), [wl.default_nodepool()])
+    if name == "host_ports_existing":
+        # ... and on existing nodes whose bound pods already hold some of the ports
+        nodes, bound = wl.existing_cluster(120, 14, types, zones)
+        _with_host_ports(bound, 6, every=5)
+        return Problem(types, _with_host_ports(wl.mixed_pods(500, 22, zones, families(types)), 7, every=2), [wl.default_nodepool()],
+                       nodes=nodes, bound=bound)
     if name == "many_claims":
         # more NodeClaims in flight than the scan order the kernel keeps in LDS (KG_ORD = 2048): 2200 pods with hostname
         # self-anti-affinity (one per node), then small pods that land on those claims and reorder them

@@ -65,13 +65,13 @@ def test_c2_full(L):
     print("C2 full: oracle %.1f ms, device %.2f ms" % (ro.res.device_ms, rg.res.device_ms))
 
 
-@pytest.mark.parametrize("name", ["c3_small", "c3_mid", "c3_large", "existing_small", "existing_mid", "existing_large", "c5_small", "c5_mid"])
+@pytest.mark.parametrize("name", ["c3_small", "c3_mid", "c3_large", "existing_small", "existing_mid", "existing_large", "c5_small", "c5_mid", "host_ports", "host_ports_existing"])
 def test_scenarios(L, name):
     """C3 topology spread / anti-affinity, existing nodes, C5 weighted NodePools with limits -- bit for bit vs the oracle."""
     check(L, scenario(name))
 
 
-@pytest.mark.parametrize("name", ["c3_small", "c3_mid", "c3_large", "existing_small", "existing_mid", "existing_large", "c5_small", "c5_mid"])
+@pytest.mark.parametrize("name", ["c3_small", "c3_mid", "c3_large", "existing_small", "existing_mid", "existing_large", "c5_small", "c5_mid", "host_ports", "host_ports_existing"])
 def test_scenarios_prefilter_path(L, name):
     """The same scenarios with the visit counters off (the production setting): prefilter + small first pass."""
     prob = scenario(name)

@@ -65,7 +65,7 @@ def test_prefilter_path_same_placements(L, n, seed):
     assert d == "", d
 
 
-@pytest.mark.parametrize("name", ["c3_small", "c3_mid", "existing_small", "existing_mid", "c5_small"])
+@pytest.mark.parametrize("name", ["c3_small", "c3_mid", "existing_small", "existing_mid", "c5_small", "host_ports", "host_ports_existing"])
 def test_scenarios(L, name):
     """C3 (zone + hostname spread, hostname anti-affinity), existing nodes first (ExistingNode.Add), C5 (weighted
     NodePools with limits, 6 zones, existing nodes charged against the limits)."""
@@ -75,7 +75,7 @@ def test_scenarios(L, name):
         assert any(k == 1 for k, _ in ro.decode()["pods"])
 
 
-@pytest.mark.parametrize("name", ["c3_small", "c3_mid", "existing_small", "c5_small"])
+@pytest.mark.parametrize("name", ["c3_small", "c3_mid", "existing_small", "c5_small", "host_ports", "host_ports_existing"])
 def test_scenarios_prefilter_path(L, name):
     """The same scenarios with the visit counters off (the production setting): prefilter + small first pass."""
     from tests.helpers import scenario
