@@ -12,6 +12,8 @@ struct kg_ctx {
   std::string last_error;
   kg_stats stats{};
   bool collect_timers = false;
+  bool wave_timers = false;   // debug: per-wave work / barrier-wait cycles per phase kind (kg_set_collect_stats bit 5)
+  bool no_fast_path = false;  // debug: keep every placement on the workgroup-wide evaluation (kg_set_collect_stats bit 4)
   int sim_block_threads = 256;  // workgroup size of k_solve for consolidation batches (one workgroup per simulation)
   int block_threads = 256;  // workgroup size of k_solve (256, 512 or 1024): 256 measured best (one wave per SIMD)
   bool collect_stats = true;  // maintain the reference-visit counters (exact; costs an extra pass per placement)

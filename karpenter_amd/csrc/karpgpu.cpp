@@ -1083,7 +1083,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   if (TWP > 256) throw Unsupported("more than 16384 instance types");
   D.tmpl_minv_mask = tmpl_minv_mask;
   D.has_ports = port_vocab.empty() ? 0 : 1;
-  D.TWP = TWP; D.NV = NV; D.stats = (stats ? 1 : 0) | (ctx->collect_timers ? 2 : 0);
+  D.TWP = TWP; D.NV = NV; D.stats = (stats ? 1 : 0) | (ctx->collect_timers ? 2 : 0) | (ctx->no_fast_path ? 4 : 0) | (ctx->wave_timers ? 8 : 0);  // (DevProblem::stats bit 2 = no wave-local evaluation)
   for (int r = 0; r < R; ++r) {
     const uint32_t g = C.act_res[r];
     const uint32_t* toff = (const uint32_t*)(CT.image.bytes.data() + CT.o_thr_off);
@@ -1124,7 +1124,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   Arena SA;
   std::vector<int64_t> remaining0(tmpl_limits0);
   std::vector<uint32_t> header(16, 0), nqueue{(uint32_t)P};
-  std::vector<uint64_t> counters(64, 0);
+  std::vector<uint64_t> counters(64 + 16 * 32, 0);  // [64..): per-wave cycle accounting (16 waves x 16 slots)
   C.o_nreq = SA.add(nreq0);
   C.o_nports = SA.add(nports0);
   C.o_cports = SA.reserve((size_t)Cmax * 8);
@@ -1307,6 +1307,8 @@ int32_t kg_set_collect_stats(kg_ctx* ctx, int32_t enabled) {
   std::lock_guard<std::mutex> lk(ctx->mu);
   ctx->collect_stats = (enabled & 1) != 0;
   ctx->collect_timers = (enabled & 2) != 0;
+  ctx->no_fast_path = (enabled & 16) != 0;
+  ctx->wave_timers = (enabled & 32) != 0;
   ctx->block_threads = (enabled & 4) ? 1024 : ((enabled & 8) ? 512 : 256);  // debugging aid: per-phase ticks of k_solve printed to stderr
   return KG_OK;
 }
@@ -1499,18 +1501,20 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
   std::vector<uint8_t> pod_kind(std::max(P, 1));
   std::vector<int32_t> pod_index(std::max(P, 1));
   std::vector<uint32_t> pod_reason(std::max(P, 1)), header(16);
-  std::vector<uint64_t> counters(64);
+  std::vector<uint64_t> counters(64 + 16 * 32);
   auto sp = [&](size_t off) { return (uint8_t*)C->state_dev.ptr + off; };
   hal::d2h(pod_kind.data(), sp(C->o_podkind), P);
   hal::d2h(pod_index.data(), sp(C->o_podindex), (size_t)P * 4);
   hal::d2h(pod_reason.data(), sp(C->o_podreason), (size_t)P * 4);
   hal::d2h(header.data(), sp(C->o_header), 64);
-  hal::d2h(counters.data(), sp(C->o_counters), 512);
+  hal::d2h(counters.data(), sp(C->o_counters), counters.size() * 8);
   if (ctx->collect_timers) {
     static const char* names[] = {"pop+ctx", "nodes", "prefilter", "load rows", "merge(+topology)", "type filter", "pick", "commit", "fresh setup", "relax"};
     for (int i = 0; i < 10; ++i) fprintf(stderr, "[kg timers] %-15s %10.3f ms\n", names[i], counters[8 + i] / 1e5);
     static const char* sub[] = {"pf: entry", "pf: loads+test", "pf: ballot+ctx fetch", "pf: barrier", "load: select", "load: loads", "merge: thread 0", "filter: thread 0", "pick: body", "commit: body"};
     for (int i = 0; i < 10; ++i) fprintf(stderr, "[kg timers]   sub %-20s %10.3f ms\n", sub[i], counters[32 + i] / 1e5);
+    static const char* fsub[] = {"fast: select", "fast: row loads", "fast: entries", "fast: resources", "fast: type filter", "fast: write / refresh", "fast: barrier wait"};
+    for (int i = 0; i < 7; ++i) fprintf(stderr, "[kg timers]   sub %-20s %10.3f ms\n", fsub[i], counters[42 + i] / 1e5);
     fprintf(stderr, "[kg timers] shader clock %.0f MHz over the launch\n", counters[25] ? counters[24] / (counters[25] / 100.0) : 0.0);
     fprintf(stderr, "[kg timers] probes (ns each): barrier %.0f, dependent global load %.0f, LDS store+2 barriers+LDS load %.0f, global store+barrier %.0f\n",
             counters[26] * 10.0 / 1000, counters[27] * 10.0 / 1000, counters[28] * 10.0 / 1000, counters[29] * 10.0 / 1000);
@@ -1520,6 +1524,19 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
             counters[56] * 10.0 / 200, counters[57] * 10.0 / 200, counters[58] * 10.0 / 200);
     fprintf(stderr, "[kg timers] survivors %llu rounds %llu false_pos %llu passes %llu\n", (unsigned long long)counters[20],
             (unsigned long long)counters[21], (unsigned long long)counters[22], (unsigned long long)counters[23]);
+  }
+  if (ctx->wave_timers) {
+    static const char* ph[] = {"prefilter", "wave-local Add", "commit", "fresh commit", "fresh setup", "workgroup Add", "nodes", "relax / ctx"};
+    for (int k = 0; k < 8; ++k) {
+      fprintf(stderr, "[kg waves] %-15s work / wait kcycles:", ph[k]);
+      for (int w = 0; w < ctx->block_threads / 64; ++w) fprintf(stderr, "  %8.0f / %-8.0f", counters[64 + w * 32 + 2 * k] / 1e3, counters[64 + w * 32 + 2 * k + 1] / 1e3);
+      fprintf(stderr, "\n");
+    }
+    for (int k = 16; k < 32; ++k) {
+      fprintf(stderr, "[kg waves] slot %2d kcycles:", k);
+      for (int w = 0; w < ctx->block_threads / 64; ++w) fprintf(stderr, "  %8.0f", counters[64 + w * 32 + k] / 1e3);
+      fprintf(stderr, "\n");
+    }
   }
   const uint32_t nclaims = header[0];
   std::vector<uint32_t> order(nclaims), c_npods(nclaims), c_meta((size_t)Ka * nclaims);

@@ -237,6 +237,8 @@ struct Row {
 // (prefilter) and the type masks of its requirement entries.
 struct PodCtx {
   int64_t preq[KG_MAXR];
+  uint32_t need, pad_;              // bit per active resource the pod requests
+  uint64_t tolw;                    // tol_tmpl word of the pod's toleration set: bit per template whose taints it tolerates
   VariantCtx vc;
   uint64_t podmask[KG_TWLDS];
   uint64_t eam[KG_MAXE][KG_TWLDS];  // e_amask rows of the pod's requirement entries
@@ -244,15 +246,17 @@ struct PodCtx {
 static_assert(sizeof(PodCtx) % 8 == 0, "PodCtx is copied as 64-bit words");
 
 struct Shared {
-  uint32_t pod, variant, best, reason;
+  uint32_t best2[2], reason, pad0_;  // first feasible existing node (slot = placement parity); reasons of the pod being placed
   uint32_t thr_lds, tw_lds, off_lds, stw_lds;
   uint32_t fresh_lim[2];            // per template attempt (alternating): some instance type is within the limits
   uint32_t feas[2], mvf[2];         // per pass (alternating): rows whose option mask stays non-empty / rows failing minValues
   uint32_t endk, need;              // end of the winner's pod-count group in the scan order; resources the pod requests
+  uint32_t thr_stride0;             // first stride of the 8-ary fit-threshold search: 8^k with 8^(k+1) >= the longest threshold list
+  uint32_t ffeas[4];                // wave-local evaluation (fast path): feasible rows of pass k in slot k & 3, slot (k + 1) & 3 cleared meanwhile
   unsigned long long ball[16];      // prefilter ballots of the current chunk of scan positions, one word per wave
   uint16_t wpos[16][KG_MAXGP];      // chunk positions of each wave's first survivors, in order
-  PodCtx pc;                        // the pod being placed
-  PodCtx nx;                        // the next pod of the queue, fetched while the current one is placed
+  PodCtx pcb[2];                    // the pod being placed / the next pod of the queue, fetched while the current one is placed
+                                    // (the roles swap at every Queue.Pop: no copy)
   uint64_t offm[KG_OFFROWS][KG_TWLDS];          // offering masks [zone * n_ct + ct]
   uint64_t stw[KG_MAXSPEC][KG_SPV][KG_TWLDS];   // value->types rows of the special keys
   // small problem tables
@@ -460,7 +464,7 @@ KG_HD uint32_t row_intersect(const DevProblem& P, Row& R, int a, int w, int off,
 // Step 3 of NodeClaim.Add for ONE pod requirement entry j: Requirements.Compatible(podReqs) + Add on that key.
 // Entries of one requirement set are on distinct keys, so the entries of a pod merge in parallel.
 template <typename BitsPtr>  // the entry's value words: LDS (VariantCtx::ebits) or the global requirement-set table
-KG_HD void row_merge_entry_from(const DevProblem& P, const Shared& sh, Row& R, uint32_t j, bool fresh, const PodEntry pe, BitsPtr pb) {
+KG_HD void row_merge_entry_from(const DevProblem& P, const Shared& sh, const PodCtx& pc, Row& R, uint32_t j, bool fresh, const PodEntry pe, BitsPtr pb) {
   const int a = pe.slot;
   const uint32_t cm = R.meta[a];
   if (!(cm & RM_PRESENT)) {
@@ -482,16 +486,16 @@ KG_HD void row_merge_entry_from(const DevProblem& P, const Shared& sh, Row& R, u
   if (pe.spec >= 0 && chg) atomic_or_u32(&R.sp_changed, 1u << pe.spec);
 }
 
-KG_HD void row_merge_entry(const DevProblem& P, const Shared& sh, Row& R, uint32_t j, bool fresh) {
-  const PodEntry pe = sh.pc.vc.ent[j];
+KG_HD void row_merge_entry(const DevProblem& P, const Shared& sh, const PodCtx& pc, Row& R, uint32_t j, bool fresh) {
+  const PodEntry pe = pc.vc.ent[j];
   // (two instantiations instead of one pointer select: a pointer that may be LDS or global memory compiles to flat loads)
-  if (pe.bits != 0xFFFF) row_merge_entry_from(P, sh, R, j, fresh, pe, sh.pc.vc.ebits + pe.bits);
-  else row_merge_entry_from(P, sh, R, j, fresh, pe, P.rs_bits + P.e_bits[pe.e]);
+  if (pe.bits != 0xFFFF) row_merge_entry_from(P, sh, pc, R, j, fresh, pe, pc.vc.ebits + pe.bits);
+  else row_merge_entry_from(P, sh, pc, R, j, fresh, pe, P.rs_bits + P.e_bits[pe.e]);
 }
 
 // Step 5 for ONE active resource: requests including the pod, and the fit threshold they select.
-KG_HD void row_merge_resource(const DevProblem& P, const Shared& sh, Row& R, int r, bool fresh) {
-  const int64_t add = sh.pc.preq[r];
+KG_HD void row_merge_resource(const DevProblem& P, const Shared& sh, const PodCtx& pc, Row& R, int r, bool fresh) {
+  const int64_t add = pc.preq[r];
   if (add == 0 && !fresh) return;
   const int64_t nr = R.req[r] + add;
   R.req[r] = nr;
@@ -503,13 +507,13 @@ KG_HD void row_merge_resource(const DevProblem& P, const Shared& sh, Row& R, int
 }
 
 // Step 4: Topology.AddRequirements -> Compatible -> Add, on the special keys of the row (one thread per row).
-KG_HD void row_topology(const DevProblem& P, const SimState& S, const Shared& sh, Row& R) {
+KG_HD void row_topology(const DevProblem& P, const SimState& S, const Shared& sh, const PodCtx& pc, Row& R) {
   const uint32_t hslot = P.N + R.c;
   for (int i = 0; i < P.nspec; ++i) R.topo[i] = ~0ull;
   uint32_t has_topo = 0;
-  for (uint32_t li = 0; li < sh.pc.vc.nlist; ++li) {
-    const ListEntry le = sh.pc.vc.lst[li].le;
-    const Group g = sh.pc.vc.lst[li].g;
+  for (uint32_t li = 0; li < pc.vc.nlist; ++li) {
+    const ListEntry le = pc.vc.lst[li].le;
+    const Group g = pc.vc.lst[li].g;
     const bool self = le.flags & LF_SELF;
     if (g.spec == 0xFF) {
       if (!topo_host(S, P, g, self, hslot)) { R.ok = 0; R.reason |= 4; return; }
@@ -549,16 +553,16 @@ KG_HD void row_topology(const DevProblem& P, const SimState& S, const Shared& sh
 // The filter is an AND of independent terms; it is cut in two halves of similar length so that two waves can each
 // run one of them for the same claim (a wave issues one instruction per ~4 cycles: the stream's length is the cost).
 // Half A: the claim's current options, the pod's entries on ordinary keys, the template's entries (fresh claim), fits.
-KG_HD uint64_t row_word_a(const DevProblem& P, const SimState& S, const Shared& sh, const Row& R, bool fresh, int w) {
+KG_HD uint64_t row_word_a(const DevProblem& P, const SimState& S, const Shared& sh, const PodCtx& pc, const Row& R, bool fresh, int w) {
   uint64_t m = S.c_mask[(size_t)w * P.Cmax + R.c];
-  const uint32_t ne = sh.pc.vc.ne;
+  const uint32_t ne = pc.vc.ne;
   // pod entries on ordinary keys
   for (uint32_t j = 0; j < ne; ++j) {
     if (!((R.ent_changed >> j) & 1)) continue;
-    const PodEntry pe = sh.pc.vc.ent[j];
+    const PodEntry pe = pc.vc.ent[j];
     if (pe.spec >= 0) continue;
     uint64_t f;
-    if (KG_UNI(sh.tw_lds)) { f = sh.pc.eam[j][w]; KG_OPAQUE64(f); } else f = P.e_amask[(size_t)pe.e * P.TW + w];
+    if (KG_UNI(sh.tw_lds)) { f = pc.eam[j][w]; KG_OPAQUE64(f); } else f = P.e_amask[(size_t)pe.e * P.TW + w];
     if ((R.ent_dne_ok >> j) & 1) f |= P.kU[(size_t)pe.slot * P.TW + w];
     m &= f;
   }
@@ -571,7 +575,7 @@ KG_HD uint64_t row_word_a(const DevProblem& P, const SimState& S, const Shared& 
       uint64_t f = P.e_amask[(size_t)e * P.TW + w];
       bool shared = false, dne_ok = false;
       for (uint32_t j = 0; j < ne; ++j)
-        if (sh.pc.vc.ent[j].slot == a) { shared = true; dne_ok = (R.ent_dne_ok >> j) & 1; }
+        if (pc.vc.ent[j].slot == a) { shared = true; dne_ok = (R.ent_dne_ok >> j) & 1; }
       if (!shared) {
         const uint64_t* tb = P.rs_bits + P.e_bits[e];
         bool anyb = false;
@@ -600,7 +604,7 @@ KG_HD uint64_t row_word_a(const DevProblem& P, const SimState& S, const Shared& 
   return m;
 }
 // Half B: the special keys (types whose value set meets the merged allowed set) and hasOffering from zone / capacity type.
-KG_HD uint64_t row_word_b(const DevProblem& P, const SimState& S, const Shared& sh, const Row& R, bool fresh, int w) {
+KG_HD uint64_t row_word_b(const DevProblem& P, const SimState& S, const Shared& sh, const PodCtx& pc, const Row& R, bool fresh, int w) {
   uint64_t m = ~0ull;
   bool off_use = fresh;
   uint64_t zmask = ~0ull, ctmask = ~0ull;
@@ -707,8 +711,8 @@ KG_HD bool row_compatible_rs(const DevProblem& P, const Shared& sh, const Row& R
 }
 
 // Topology.Record for a pod placed on the claim of row R (after the commit of its requirements)
-KG_HD void row_record_topology(const DevProblem& P, const SimState& S, const Shared& sh, const Row& R) {
-  const Variant& v = sh.pc.vc.v;
+KG_HD void row_record_topology(const DevProblem& P, const SimState& S, const Shared& sh, const PodCtx& pc, const Row& R) {
+  const Variant& v = pc.vc.v;
   const uint32_t hslot = P.N + R.c;
   for (uint32_t li = 0; li < v.record_cnt; ++li) {
     const ListEntry le = P.lists[v.record_off + li];
@@ -744,20 +748,20 @@ KG_HD void claim_refresh_head(const DevProblem& P, const SimState& S, const Shar
 
 // ------------------------------------------------------------------ ExistingNode.Add for node n (scan position)
 template <bool COMMIT>
-KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, uint32_t n, uint32_t* reason) {
-  const Variant& v = sh.pc.vc.v;
+KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, const PodCtx& pc, uint32_t n, uint32_t* reason) {
+  const Variant& v = pc.vc.v;
   const uint32_t wi = n >> 6, bi = n & 63;
   if ((S.excl[wi] >> bi) & 1) return false;  // a candidate of this simulation: not a state node
   if (!((P.ntol[(size_t)v.tolset * P.NW + wi] >> bi) & 1)) { *reason |= 1; return false; }
-  if (P.has_ports && (S.nports[n] & sh.pc.vc.hp_conf)) { *reason |= 2; return false; }  // HostPortUsage.Conflicts
+  if (P.has_ports && (S.nports[n] & pc.vc.hp_conf)) { *reason |= 2; return false; }  // HostPortUsage.Conflicts
   // resources first (cheap reject), as upstream does
   for (int r = 0; r < P.R; ++r) {
-    if (sh.pc.preq[r] != 0 && S.nreq[(size_t)r * P.N + n] + sh.pc.preq[r] > P.navail[(size_t)r * P.N + n]) { *reason |= 64; return false; }
+    if (pc.preq[r] != 0 && S.nreq[(size_t)r * P.N + n] + pc.preq[r] > P.navail[(size_t)r * P.N + n]) { *reason |= 64; return false; }
   }
   if (!((P.nlab[(size_t)v.rs * P.NW + wi] >> bi) & 1)) { *reason |= 2; return false; }
-  for (uint32_t li = 0; li < sh.pc.vc.nlist; ++li) {
-    const ListEntry le = sh.pc.vc.lst[li].le;
-    const Group g = sh.pc.vc.lst[li].g;
+  for (uint32_t li = 0; li < pc.vc.nlist; ++li) {
+    const ListEntry le = pc.vc.lst[li].le;
+    const Group g = pc.vc.lst[li].g;
     const bool self = le.flags & LF_SELF;
     if (g.spec == 0xFF) {
       if (!topo_host(S, P, g, self, n)) { *reason |= 4; return false; }
@@ -770,8 +774,8 @@ KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, u
     if (!o.ok || !((o.opts >> d) & 1)) { *reason |= 4; return false; }
   }
   if (COMMIT) {
-    for (int r = 0; r < P.R; ++r) if (sh.pc.preq[r] != 0) S.nreq[(size_t)r * P.N + n] += sh.pc.preq[r];
-    if (P.has_ports) S.nports[n] |= sh.pc.vc.hp_use;
+    for (int r = 0; r < P.R; ++r) if (pc.preq[r] != 0) S.nreq[(size_t)r * P.N + n] += pc.preq[r];
+    if (P.has_ports) S.nports[n] |= pc.vc.hp_use;
     for (uint32_t li = 0; li < v.record_cnt; ++li) {
       const ListEntry le = P.lists[v.record_off + li];
       const Group g = P.groups[le.g];
@@ -813,25 +817,279 @@ KG_HD void ord_set(const SimState& S, Shared& sh, const DevProblem& P, bool lds,
   if (lds) sh.ord[buf][p] = v; else S.ordg[(size_t)buf * P.Cmax + p] = v;
 }
 
-// one Queue.Pop's worth of pod context, global -> sh.nx (each thread moves its share; needs a barrier afterwards)
+// one Queue.Pop's worth of pod context, global -> the buffer of the next pod (each thread moves its share; needs a barrier afterwards)
 template <int NT>
-KG_HD void ctx_fetch(const DevProblem& P, Shared& sh, int tid, uint32_t pod, uint32_t variant) {
+KG_HD void ctx_fetch(const DevProblem& P, PodCtx& nx, int tid, uint32_t pod, uint32_t variant) {
   const uint64_t* src = (const uint64_t*)(P.vctx + variant);
-  uint64_t* dst = (uint64_t*)&sh.nx.vc;
+  uint64_t* dst = (uint64_t*)&nx.vc;
   for (uint32_t i = tid; i < sizeof(VariantCtx) / 8; i += NT) dst[i] = src[i];
   if (tid >= NT - KG_MAXR) {
     const int r = tid - (NT - KG_MAXR);
-    sh.nx.preq[r] = r < P.R ? P.preq[(size_t)pod * P.R + r] : 0;
+    nx.preq[r] = r < P.R ? P.preq[(size_t)pod * P.R + r] : 0;
   }
+  if (tid == NT - KG_MAXR - 2) {
+    uint32_t nd = 0;
+    for (int r = 0; r < P.R; ++r) if (P.preq[(size_t)pod * P.R + r] != 0) nd |= 1u << r;
+    nx.need = nd;
+  }
+  if (tid == NT - KG_MAXR - 1) nx.tolw = P.tol_tmpl[P.vctx[variant].v.tolset];
   if (tid >= NT / 2 && tid < NT / 2 + KG_TWLDS && P.TW <= KG_TWLDS)  // zero-padded: the prefilter ANDs all KG_TWLDS words
-    sh.nx.podmask[tid - NT / 2] = tid - NT / 2 < P.TW ? P.podmask[(size_t)variant * P.TW + (tid - NT / 2)] : 0;
+    nx.podmask[tid - NT / 2] = tid - NT / 2 < P.TW ? P.podmask[(size_t)variant * P.TW + (tid - NT / 2)] : 0;
   if (tid >= 96 && tid < 96 + KG_MAXE * KG_TWLDS && P.TW <= KG_TWLDS) {
     // e_amask rows of the pod's requirement entries (entry ids straight from the global record: same round trip)
     const uint32_t j = (uint32_t)(tid - 96) / KG_TWLDS, w = (uint32_t)(tid - 96) % KG_TWLDS;
     const VariantCtx* gv = P.vctx + variant;
-    if (j < gv->ne && w < (uint32_t)P.TW) sh.nx.eam[j][w] = P.e_amask[(size_t)gv->ent[j].e * P.TW + w];
+    if (j < gv->ne && w < (uint32_t)P.TW) nx.eam[j][w] = P.e_amask[(size_t)gv->ent[j].e * P.TW + w];
   }
 }
+
+
+#if KG_DEVICE_ONLY
+// ------------------------------------------------------------------ NodeClaim.Add by ONE wave, the claim row in registers
+// The common placement (pod without topology groups, no minValues NodePool, tables staged in LDS) does not need the
+// workgroup for the exact test: lane i of a wave holds word i of the claim's requirement row (lane a its meta word for
+// key a, lane r its requests of resource r, lane w word w of its option mask), the pod's entries are merged one after the
+// other with ballots for the per-key reductions, the fit thresholds come from a 64-wide search, and the type filter runs
+// on lanes [0, TW).  Each wave evaluates a different survivor of the prefilter and no barrier separates load, merge,
+// filter and verdict.  Same arithmetic as row_merge_entry_from / row_merge_resource / row_word_a / row_word_b.
+__device__ __forceinline__ uint32_t rl32(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+__device__ __forceinline__ uint64_t rl64(uint64_t v, uint32_t lane) {
+  return ((uint64_t)rl32((uint32_t)(v >> 32), lane) << 32) | rl32((uint32_t)v, lane);
+}
+__device__ __forceinline__ int64_t wave_max_i64(int64_t v) {
+#pragma unroll
+  for (int s = 32; s; s >>= 1) {
+    const int64_t o = __shfl_xor(v, s, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// first scan position whose claim holds more than k pods (= end of the k-pod group), by 64-ary search
+__device__ __forceinline__ uint32_t wave_group_end(const SimState& S, const Shared& sh, const DevProblem& P, bool lds, uint32_t buf, uint32_t nclaims, uint32_t k,
+                                                   uint32_t lane) {
+  uint32_t stride = 1;
+  while ((unsigned long long)stride * 64 < nclaims) stride *= 64;
+  uint32_t lo = 0;
+  while (true) {
+    const unsigned long long q = (unsigned long long)lo + (unsigned long long)lane * stride;
+    bool f = true;
+    if (q < nclaims) f = (uint32_t)(ord_get(S, sh, P, lds, buf, (uint32_t)q) >> 32) > k;
+    const unsigned long long b = __ballot(f);
+    const uint32_t L = b ? (uint32_t)(__ffsll(b) - 1) : 64u;
+    if (stride == 1) return lo + L;
+    if (L == 0) return lo;
+    lo = lo + (L - 1) * stride + 1;
+    stride /= 64;
+  }
+}
+
+// evaluates claim c (scan position pos, order entry oe) for the pod in sh.pc; on success the merged row goes to
+// sh.rows[slot] (with the end of the claim's pod-count group in Row::pad_), the candidate option mask to S.scratch and
+// bit `slot` of *feas is set
+__device__ __forceinline__ void fast_eval_wave(const DevProblem& P, const SimState& S, Shared& sh, const PodCtx& pc, uint32_t lane, uint32_t slot, uint32_t c, uint32_t pos,
+                                               unsigned long long oe, uint32_t need, uint32_t* feas, bool ord_lds, uint32_t ob, uint32_t nclaims,
+                                               bool WT, unsigned long long* wt, unsigned long long& wt_last) {
+#define KG_FT(k) do { if (WT) { const unsigned long long n_ = clock64(); if (wt_last) wt[(k) - 22] += n_ - wt_last; wt_last = n_; } } while (0)
+  const uint32_t Ka = (uint32_t)P.Ka, Wa = (uint32_t)P.Wa, NR = (uint32_t)P.R, TW = (uint32_t)P.TW;
+  const size_t Cmax = (size_t)P.Cmax;
+  const uint32_t rg = lane >> 3;  // resources are handled by groups of 8 lanes: lanes [8r, 8r + 8) <-> active resource r
+  // ---- one round trip: the claim's row
+  uint32_t meta = 0;
+  uint64_t bits = 0, cm = 0;
+  int64_t req = 0;
+  if (lane < Ka) meta = S.c_meta[(size_t)lane * Cmax + c];
+  if (lane < Wa) bits = S.c_bits[(size_t)lane * Cmax + c];
+  if (rg < NR) req = S.c_req[(size_t)rg * Cmax + c];
+  if (lane < TW) cm = S.c_mask[(size_t)lane * Cmax + c];
+  const uint32_t tm_v = S.c_tmpl[c];
+  const uint32_t stamp_v = S.c_stamp[c];
+  uint64_t ports_v = 0;
+  if (P.has_ports) ports_v = S.c_ports[c];
+  // ---- while the row is on its way: the small tables this evaluation indexes by a scalar (lane i holds entry i),
+  // and the end of the claim's pod-count group (where it moves if it takes the pod)
+  uint4 pe4;
+  pe4.x = pe4.y = pe4.z = pe4.w = 0;
+  if (lane < KG_MAXE) pe4 = ((const uint4*)pc.vc.ent)[lane];
+  static_assert(sizeof(PodEntry) == 16, "PodEntry is read as one 16-byte word");
+  uint32_t spa = 0, spoff = 0;
+  if (lane < (uint32_t)P.nspec) { spa = sh.spec_slot[lane]; spoff = sh.aoff[spa]; }
+  uint32_t tn = 0, tbase = 0, toff = 0;
+  int64_t add = 0;
+  if (rg < NR) { tn = sh.a_thr_n[rg]; tbase = sh.thr_base[rg]; toff = sh.a_thr_off[rg]; add = pc.preq[rg]; }
+  const uint32_t ne = KG_UNI(pc.vc.ne);
+  const uint64_t tolw = KG_UNI64(pc.tolw), hp_conf = P.has_ports ? KG_UNI64(pc.vc.hp_conf) : 0ull;
+  const uint32_t hcok = KG_UNI(pc.vc.v.host_claim_ok);
+  const uint32_t gend = wave_group_end(S, sh, P, ord_lds, ob, nclaims, (uint32_t)(oe >> 32), lane);
+  KG_FT(42);
+  const uint32_t tm = KG_UNI(tm_v), stamp = KG_UNI(stamp_v);
+  bool ok = ((tolw >> tm) & 1) && hcok && !(KG_UNI64(ports_v) & hp_conf);
+  const int64_t req0 = req;
+  const uint64_t cm0 = cm;
+  KG_FT(43);
+  // ---- step 3: the pod's requirement entries, one after the other (distinct keys)
+  uint32_t ent_changed = 0, ent_dne_ok = 0, sp_changed = 0, ent_ord = 0;
+  for (uint32_t j = 0; j < ne && ok; ++j) {
+    // PodEntry {e, meta, aoff:16 bits:16, slot:8 spec:8 w:8 opc:8}
+    const uint32_t pm = rl32(pe4.y, j), ab = rl32(pe4.z, j), sw = rl32(pe4.w, j);
+    const uint32_t aoff = ab & 0xFFFF, pbits = ab >> 16, a = sw & 0xFF, w = (sw >> 16) & 0xFF, opc = sw >> 24;
+    const int spec = (int)(int8_t)((sw >> 8) & 0xFF);
+    if (spec < 0) ent_ord |= 1u << j;
+    const uint32_t cma = rl32(meta, a);
+    const bool inr = lane >= aoff && lane < aoff + w;
+    uint64_t y = 0;
+    if (pbits != 0xFFFF) { if (inr) { y = pc.vc.ebits[pbits + lane - aoff]; KG_OPAQUE64(y); } }
+    else if (inr) y = P.rs_bits[P.e_bits[rl32(pe4.x, j)] + lane - aoff];
+    if (!(cma & RM_PRESENT)) {
+      if (!((P.well_known_slots >> a) & 1) && !op_neg((int)opc)) { ok = false; break; }
+      if (op_neg((int)opc)) ent_dne_ok |= 1u << j;
+      ent_changed |= 1u << j;
+      if (spec >= 0) sp_changed |= 1u << spec;
+      if (inr) bits = y;
+      if (lane == a) meta = pm;
+      continue;
+    }
+    const bool xc = cma & RM_COMPL, yc = pm & RM_COMPL;
+    const uint32_t gt = rm_gt(cma) > rm_gt(pm) ? rm_gt(cma) : rm_gt(pm);
+    const uint32_t lt = min_nz(rm_lt(cma), rm_lt(pm));
+    const bool dne = gt && lt && P.gtval[P.bnd_off[a] + gt - 1] >= P.ltval[P.bnd_off[a] + lt - 1];
+    const uint32_t mm = (xc && yc && !dne) ? rm_make(true, gt, lt) : rm_make(false, 0, 0);
+    const uint64_t x = bits;
+    uint64_t r = x;
+    if (inr) {
+      r = dne ? 0 : ((xc && yc) ? (x | y) : (xc ? (y & ~x) : (yc ? (x & ~y) : (x & y))));
+      if (!dne && gt) r &= P.gtmask[P.bndmask_off[a] + (size_t)(gt - 1) * w + (lane - aoff)];
+      if (!dne && lt) r &= P.ltmask[P.bndmask_off[a] + (size_t)(lt - 1) * w + (lane - aoff)];
+    }
+    const bool anyb = __ballot(inr && r != 0) != 0, canyb = __ballot(inr && x != 0) != 0;
+    const bool chg = mm != cma || __ballot(inr && r != x) != 0;
+    if (inr) bits = r;
+    if (lane == a) meta = mm;
+    const int cop = opclass(xc, canyb);
+    const bool empty = !(mm & RM_COMPL) && !anyb;
+    if (empty && !(op_neg((int)opc) && op_neg(cop))) { ok = false; break; }
+    if (op_neg(opclass(mm & RM_COMPL, anyb))) ent_dne_ok |= 1u << j;
+    if (chg) ent_changed |= 1u << j;
+    if (spec >= 0 && chg) sp_changed |= 1u << spec;
+  }
+  KG_FT(44);
+  // ---- step 5: requests including the pod; the fit threshold of every resource at once, by 8-ary search in its lanes
+  const int64_t nr = req + add;
+  req = nr;
+  const bool ruse = rg < NR && ((need >> rg) & 1) && nr > 0;
+  uint32_t tidx = 0;
+  {
+    uint32_t lo = 0;
+    const uint32_t j8 = lane & 7, sh8 = lane & 56u;
+    for (uint32_t stride = KG_UNI(sh.thr_stride0); stride; stride >>= 3) {
+      const uint32_t q = lo + j8 * stride;
+      bool f = true;
+      if (q < tn) f = sh.thr_val[tbase + q] >= nr;
+      const uint32_t gb = (uint32_t)(__ballot(f) >> sh8) & 0xFFu;
+      const uint32_t L = gb ? (uint32_t)__builtin_ctz(gb) : 8u;
+      if (stride == 1) lo = lo + L;
+      else if (L != 0) lo = lo + (L - 1) * stride + 1;
+    }
+    tidx = lo;
+  }
+  const unsigned long long useb = __ballot(ruse && (lane & 7) == 0);   // bit 8r: resource r decides
+  const bool thr_none = __ballot(ruse && tidx >= tn) != 0;
+  const uint32_t trow = toff + (tidx < tn ? tidx : 0);
+  KG_FT(45);
+  // ---- step 6: the instance-type filter on lanes [0, TW)
+  bool feasible = false;
+  uint64_t m = cm;
+  if (ok && !thr_none) {
+    const uint32_t w = lane < TW ? lane : 0;
+    // fits (independent loads first)
+    uint64_t tmk[KG_MAXR];
+#pragma unroll
+    for (int r = 0; r < KG_MAXR; ++r) {
+      tmk[r] = ~0ull;
+      if ((useb >> (8 * r)) & 1) tmk[r] = P.thr_mask[(size_t)rl32(trow, 8 * r) * TW + w];
+    }
+    // pod entries on ordinary keys
+    for (uint32_t em = ent_changed & ent_ord; em; em &= em - 1) {
+      const uint32_t j = (uint32_t)__builtin_ctz(em);
+      uint64_t f = pc.eam[j][w];
+      KG_OPAQUE64(f);
+      if ((ent_dne_ok >> j) & 1) f |= P.kU[(size_t)(rl32(pe4.w, j) & 0xFF) * TW + w];
+      m &= f;
+    }
+    // special keys and hasOffering: nothing to do unless the pod changed one of them
+    if (sp_changed) {
+      bool off_use = false;
+      uint64_t zmask = ~0ull, ctmask = ~0ull;
+      for (int i = 0; i < P.nspec; ++i) {
+        const uint32_t a = rl32(spa, (uint32_t)i);
+        SReq sp;
+        sp.meta = rl32(meta, a);
+        const bool present = sp.meta & RM_PRESENT;
+        sp.word = present ? rl64(bits, rl32(spoff, (uint32_t)i)) : 0;
+        const bool changed = (sp_changed >> i) & 1;
+        const uint64_t hm = has_mask1(P, (int)a, sp);
+        if (changed && present) {
+          uint64_t f = P.kN[(size_t)a * TW + w];
+          if (op_neg(opclass(sp.meta & RM_COMPL, sp.word != 0))) f |= P.kU[(size_t)a * TW + w];
+          for (uint64_t q = hm & ((1ull << KG_SPV) - 1); q; q &= q - 1) { uint64_t g = sh.stw[i][ctz64(q)][w]; KG_OPAQUE64(g); f |= g; }
+          m &= f;
+        }
+        if (i == P.slot_zone || i == P.slot_ct || i == P.slot_zid) off_use = off_use || changed;
+        if (i == P.slot_zone) zmask &= hm;
+        if (i == P.slot_ct) ctmask = hm;
+        if (i == P.slot_zid) {
+          uint64_t zm = 0;
+          for (int z = 0; z < P.n_zone_vals; ++z) {
+            const uint8_t zid = P.zone_zid[z];
+            if (zid == 0xFF || ((hm >> zid) & 1)) zm |= 1ull << z;
+          }
+          zmask &= zm;
+        }
+      }
+      if (off_use) {
+        uint64_t f = 0;
+        for (int z = 0; z < P.n_zone_vals; ++z) {
+          if (!((zmask >> z) & 1)) continue;
+          for (int ct = 0; ct < P.n_ct_vals; ++ct)
+            if ((ctmask >> ct) & 1) { uint64_t g = sh.offm[z * P.n_ct_vals + ct][w]; KG_OPAQUE64(g); f |= g; }
+        }
+        m &= f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < KG_MAXR; ++r) m &= tmk[r];
+    feasible = __ballot(lane < TW && m != 0) != 0;
+  }
+  KG_FT(46);
+  if (feasible) {
+    Row& R = sh.rows[slot];
+    if (lane < KG_MAXKA) R.meta[lane] = meta;
+    R.bits[lane] = bits;
+    if ((lane & 7) == 0) R.req[rg] = req;
+    if (lane < TW) S.scratch[(size_t)lane * Cmax + c] = m;
+    if (lane == 63) {
+      R.c = c; R.tmpl = tm; R.ok = 1; R.reason = 0; R.pos = pos; R.tv = 0; R.npods = (uint32_t)(oe >> 32); R.stamp = stamp; R.pad_ = gend;
+      atomic_or_u32(feas, 1u << slot);
+    }
+  } else if (KG_UNI(S.c_hstamp[c]) != stamp) {
+    // the prefilter let an infeasible claim through: recompute its headroom (its options changed since the last time)
+    for (uint32_t r = 0; r < NR; ++r) {
+      const int64_t* al = P.alloc + (size_t)KG_UNI(sh.a_res[r]) * P.T;
+      int64_t mx = 0;
+      for (uint32_t w = 0; w < TW; ++w) {
+        const uint64_t mw = rl64(cm0, w);
+        if ((mw >> lane) & 1) { const int64_t v = al[w * 64 + lane]; mx = v > mx ? v : mx; }
+      }
+      mx = wave_max_i64(mx);
+      const int64_t rq = (int64_t)rl64((uint64_t)req0, 8 * r);
+      if (lane == 0) S.c_head[(size_t)r * Cmax + c] = mx - rq;
+    }
+    if (lane == 0) S.c_hstamp[c] = stamp;
+  }
+  KG_FT(47);
+#undef KG_FT
+}
+#endif
 
 // ------------------------------------------------------------------ one Solve by one workgroup
 // NT = threads in the workgroup.  `sh` lives in LDS.
@@ -852,6 +1110,17 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
 #define KG_T(i) do { if (TIMERS) { KG_FOR_THREADS(tid, NT) { if (tid == 0) { const unsigned long long n_ = now_ticks(); if (t_mark) S.counters[8 + (i)] += n_ - t_mark; t_mark = n_; } } } } while (0)
   // (inside a phase body: thread 0's own progress, counters[32 + k])
 #define KG_ST(k) do { if (TIMERS && tid == 0) { const unsigned long long n_ = now_ticks(); if (t_mark) S.counters[32 + (k)] += n_ - t_mark; t_mark = n_; } } while (0)
+  // per-wave cycle accounting (stats & 8): work / barrier wait of every phase kind, kept in registers, written at the end
+#if KG_DEVICE_ONLY
+  const bool WT = (P.stats & 8) != 0;
+  unsigned long long wt_last = 0, wt[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) wt[i] = 0;
+#define KG_W(k) do { if (WT) { const unsigned long long n_ = clock64(); if (wt_last) wt[k] += n_ - wt_last; wt_last = n_; } } while (0)
+#else
+#define KG_W(k) ((void)0)
+#endif
+#define KG_SYNCW(ph) do { KG_W(2 * (ph)); KG_SYNC(); KG_W(2 * (ph) + 1); } while (0)
   const uint32_t TWP = (uint32_t)P.TWP;      // threads per evaluation group (power of two >= max(TW, 16))
   const uint32_t GP = (NT / TWP) < (uint32_t)KG_MAXGP ? (NT / TWP) : (uint32_t)KG_MAXGP;  // claims evaluated per pass
   static_assert(NT % 64 == 0 && NT / 64 <= 16, "one ballot word per wave");
@@ -868,7 +1137,12 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
       uint32_t tot = 0;
       for (int r = 0; r < P.R; ++r) { sh.thr_base[r] = tot; tot += sh.a_thr_n[r]; }
       sh.thr_lds = tot <= (uint32_t)KG_THR_LDS;
-      sh.reason = 0; sh.endk = 0; sh.feas[0] = sh.feas[1] = 0; sh.mvf[0] = sh.mvf[1] = 0;
+      uint32_t nmax = 1, st0 = 1;
+      for (int r = 0; r < P.R; ++r) nmax = sh.a_thr_n[r] > nmax ? sh.a_thr_n[r] : nmax;
+      while (st0 * 8 < nmax) st0 *= 8;
+      sh.thr_stride0 = st0;
+      sh.reason = 0; sh.best2[0] = sh.best2[1] = KG_NOIDX; sh.endk = 0; sh.feas[0] = sh.feas[1] = 0; sh.mvf[0] = sh.mvf[1] = 0;
+      sh.ffeas[0] = sh.ffeas[1] = sh.ffeas[2] = sh.ffeas[3] = 0;
     }
     for (int a = tid; a < P.Ka; a += NT) { sh.aoff[a] = P.aoff[a]; sh.aw[a] = P.aw[a]; sh.slot2spec[a] = P.slot2spec[a]; }
     for (int i = tid; i < P.nspec; i += NT) sh.spec_slot[i] = P.spec_slot[i];
@@ -913,6 +1187,9 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
   uint4 qe_next;
   qe_next.x = qe_next.y = qe_next.z = qe_next.w = 0;
   uint32_t passno = 0;
+  uint32_t cur = 0, placement = 0;                 // buffer of sh.pcb that holds the pod being placed; placements so far
+  uint32_t fpass = 0, endk_fast = 0;                // wave-local passes so far; the winner's group end when such a pass found it
+  bool fast_win = false;
   while (true) {
     // ---- Queue.Pop
     if (qlen == 0) break;
@@ -923,29 +1200,23 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     const uint32_t pod = qe.x, variant = qe.y;
     qhead = (qhead + 1) % QCAP;
     qlen -= 1;
-    // ---- pod context: fetched during the previous placement, or now
+    // ---- pod context: fetched during the previous placement into the other buffer, or now; the buffers swap roles
     if (!ctx_ready) {
-      KG_FOR_THREADS(tid, NT) { ctx_fetch<NT>(P, sh, tid, pod, variant); }
-      KG_SYNC();
+      KG_FOR_THREADS(tid, NT) { ctx_fetch<NT>(P, sh.pcb[cur ^ 1], tid, pod, variant); }
+      KG_SYNCW(7);
     }
-    KG_FOR_THREADS(tid, NT) {
-      const uint64_t* src = (const uint64_t*)&sh.nx;
-      uint64_t* dst = (uint64_t*)&sh.pc;
-      for (uint32_t i = tid; i < sizeof(PodCtx) / 8; i += NT) dst[i] = src[i];
-      if (tid == NT - 1) {
-        sh.pod = pod; sh.variant = variant; sh.best = KG_NOIDX; sh.reason = 0;
-        uint32_t nd = 0;  // resources the pod requests
-        for (int r = 0; r < P.R; ++r) if (sh.nx.preq[r] != 0) nd |= 1u << r;
-        sh.need = nd;
-      }
-    }
+    cur ^= 1;
+    placement += 1;
+    const PodCtx& pc = sh.pcb[cur];
+    PodCtx& nx = sh.pcb[cur ^ 1];
+    const uint32_t bslot = placement & 1;   // sh.best2 slot of this placement; the other one is reset meanwhile
+    KG_FOR_THREADS(tid, NT) { if (tid == 0) sh.reason = 0; }  // (only thread 0 ever touches it)
     // the entry behind the head is settled (a push lands behind it) when at least one pod is left
     have_next = qlen >= 1;
     if (have_next) qe_next = ((const KG_GLOBAL uint4*)S.queue)[qhead];  // (made uniform when it is popped)
     bool want_pf = have_next;
     ctx_ready = false;
-    KG_SYNC();
-    const uint32_t need = KG_UNI(sh.need);
+    const uint32_t need = KG_UNI(pc.need);
     KG_T(0);
     // ---- existing nodes, first feasible in scan order
     for (uint32_t base = 0; base < (uint32_t)P.N; base += NT) {
@@ -953,25 +1224,27 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
         const uint32_t n = base + tid;
         if (n < (uint32_t)P.N) {
           uint32_t reason = 0;
-          if (eval_node<false>(P, S, sh, n, &reason)) atomic_min_u32(&sh.best, n);
+          if (eval_node<false>(P, S, sh, pc, n, &reason)) atomic_min_u32(&sh.best2[bslot], n);
         }
-        if (want_pf) ctx_fetch<NT>(P, sh, tid, qe_next.x, qe_next.y);
+        if (tid == 0) sh.best2[bslot ^ 1] = KG_NOIDX;  // (last read one placement ago)
+        if (want_pf) ctx_fetch<NT>(P, nx, tid, qe_next.x, qe_next.y);
       }
       if (want_pf) { want_pf = false; ctx_ready = true; }
-      KG_SYNC();
-      if (KG_UNI(sh.best) != KG_NOIDX) break;
+      KG_SYNCW(6);
+      if (KG_UNI(sh.best2[bslot]) != KG_NOIDX) break;
     }
-    if (KG_UNI(sh.best) != KG_NOIDX) {
+    if (P.N > 0 && KG_UNI(sh.best2[bslot]) != KG_NOIDX) {
       KG_FOR_THREADS(tid, NT) {
         if (tid == 0) {
           uint32_t reason = 0;
-          eval_node<true>(P, S, sh, sh.best, &reason);
+          const uint32_t bn = sh.best2[bslot];
+          eval_node<true>(P, S, sh, pc, bn, &reason);
           S.pod_kind[pod_row(S, pod)] = 1;
-          S.pod_index[pod_row(S, pod)] = (int32_t)sh.best;
-          if (STATS) S.counters[0] += sh.best + 1;
+          S.pod_index[pod_row(S, pod)] = (int32_t)bn;
+          if (STATS) S.counters[0] += bn + 1;
         }
       }
-      KG_SYNC();
+      KG_SYNCW(6);
       KG_T(1);
       continue;
     }
@@ -986,12 +1259,19 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     // accepts the pod ends the scan.  Stage 1 runs the same NodeClaim.Add on one freshly materialised claim per template.
     last_c = KG_NOIDX; last_new = 0;
     uint32_t stage = 0, tnext = 0, base = 0, result = 0, win_g = 0;
+    fast_win = false;
+#if KG_DEVICE_ONLY
+    // the wave-local NodeClaim.Add covers pods without topology groups when the tables are staged in LDS
+    const bool fast_pod = !STATS && !(P.stats & 4) && P.tmpl_minv_mask == 0 && KG_UNI(pc.vc.nlist) == 0 && P.TW <= KG_TWLDS && P.Ka <= KG_MAXKA &&
+                          P.Wa <= 64 && KG_UNI(sh.thr_lds) && KG_UNI(sh.stw_lds) && KG_UNI(sh.off_lds);
+#endif
     while (stage != 2) {
       const bool fresh = stage == 1;
       uint32_t nsv = 0;
       if (!fresh) {
         if (base >= nclaims) { stage = (nclaims < (uint32_t)P.Cmax && P.NP > 0) ? 1 : 2; continue; }
         const uint32_t chunk = nclaims - base < (uint32_t)NT ? nclaims - base : (uint32_t)NT;
+        KG_W(16);
         KG_FOR_THREADS(tid, NT) {
           bool ok = false;
           KG_ST(0);
@@ -1016,25 +1296,27 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
 #pragma unroll
                 for (int w = 0; w < KG_TWLDS; ++w) if (w < P.TW) mk[w] = S.c_mask[(size_t)w * P.Cmax + c];
 #pragma unroll
-                for (int w = 0; w < KG_TWLDS; ++w) any |= mk[w] & sh.pc.podmask[w];
+                for (int w = 0; w < KG_TWLDS; ++w) any |= mk[w] & pc.podmask[w];
               } else {
-                const uint64_t* pm = P.podmask + (size_t)sh.variant * P.TW;
+                const uint64_t* pm = P.podmask + (size_t)variant * P.TW;
                 for (int w = 0; w < P.TW; ++w) any |= S.c_mask[(size_t)w * P.Cmax + c] & pm[w];
               }
-              ok = ((P.tol_tmpl[sh.pc.vc.v.tolset] >> tm) & 1) && sh.pc.vc.v.host_claim_ok && any != 0;
-              if (P.has_ports) ok = ok && !(S.c_ports[c] & sh.pc.vc.hp_conf);
+              ok = ((pc.tolw >> tm) & 1) && pc.vc.v.host_claim_ok && any != 0;
+              if (P.has_ports) ok = ok && !(S.c_ports[c] & pc.vc.hp_conf);
 #pragma unroll
-              for (int r = 0; r < KG_MAXR; ++r) ok = ok && (!((need >> r) & 1) || hd[r] >= sh.pc.preq[r]);
+              for (int r = 0; r < KG_MAXR; ++r) ok = ok && (!((need >> r) & 1) || hd[r] >= pc.preq[r]);
             }
           }
           KG_ST(1);
+          KG_W(17);
           const uint32_t rank = wave_ballot_store(sh.ball, tid, ok);
           if (ok && rank < (uint32_t)KG_MAXGP) sh.wpos[tid >> 6][rank] = (uint16_t)tid;
-          if (want_pf) ctx_fetch<NT>(P, sh, tid, qe_next.x, qe_next.y);
+          KG_W(18);
+          if (want_pf) ctx_fetch<NT>(P, nx, tid, qe_next.x, qe_next.y);
           KG_ST(2);
         }
         if (want_pf) { want_pf = false; ctx_ready = true; }
-        KG_SYNC();
+        KG_SYNCW(0);
         { KG_FOR_THREADS(tid, NT) { KG_ST(3); } }
 #pragma unroll
         for (int i = 0; i < NT / 64; ++i) nsv += (uint32_t)popc64(KG_UNI64(sh.ball[i]));
@@ -1051,8 +1333,8 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
             sh.fresh_lim[fl] = 0;
             R.c = c; R.tmpl = (uint32_t)t; R.reason = 0; R.pos = nclaims; R.tv = 0; R.ent_changed = 0; R.ent_dne_ok = 0; R.sp_changed = 0; R.thr_use = 0;
             R.npods = 0; R.stamp = 0;
-            R.ok = ((P.tol_tmpl[sh.pc.vc.v.tolset] >> t) & 1) && sh.pc.vc.v.host_claim_ok;
-            if (!R.ok) R.reason = ((P.tol_tmpl[sh.pc.vc.v.tolset] >> t) & 1) ? 2u : 1u;
+            R.ok = ((pc.tolw >> t) & 1) && pc.vc.v.host_claim_ok;
+            if (!R.ok) R.reason = ((pc.tolw >> t) & 1) ? 2u : 1u;
             sh.feas[passno & 1] = 0; sh.mvf[passno & 1] = 0;
           }
           for (int a = tid; a < P.Ka; a += NT) R.meta[a] = 0;
@@ -1061,7 +1343,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
           // hostname placeholder registered for this attempt: hcount rows of slot N+c start at zero
           for (int gh = tid; gh < P.GH; gh += NT) S.hcount[(size_t)gh * P.H + P.N + c] = 0;
         }
-        KG_SYNC();
+        KG_SYNCW(4);
         KG_FOR_THREADS(tid, NT) {
           Row& R = sh.rows[0];
           for (int w = tid; w < P.TW; w += NT) {
@@ -1085,7 +1367,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
             for (int i = 0; i < sh.aw[a]; ++i) R.bits[sh.aoff[a] + i] = P.rs_bits[P.e_bits[e] + i];
           }
         }
-        KG_SYNC();
+        KG_SYNCW(4);
         nsv = KG_UNI(sh.fresh_lim[fl]) ? 1 : 0;
         KG_T(8);
       }
@@ -1093,6 +1375,43 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
       uint32_t lo = 0;
       bool found = false;
       while (lo < nsv && !found) {
+#if KG_DEVICE_ONLY
+        if (fast_pod && !fresh) {
+          // one survivor per wave, no barrier inside the evaluation
+          const uint32_t nrow = nsv - lo < (uint32_t)(NT / 64) ? nsv - lo : (uint32_t)(NT / 64);
+          const uint32_t fpar = fpass & 3;
+          fpass += 1;
+          {
+            const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+            if (tid == 0) sh.ffeas[(fpar + 1) & 3] = 0;
+            if (wave < nrow) {
+              uint32_t rem = lo + wave, wv = 0;
+              bool hit = false;
+#pragma unroll
+              for (int i = 0; i < NT / 64; ++i) {
+                const uint32_t pc = (uint32_t)popc64(KG_UNI64(sh.ball[i]));
+                if (!hit && rem < pc) { wv = (uint32_t)i; hit = true; }
+                if (!hit) rem -= pc;
+              }
+              const uint32_t cpos = KG_UNI(rem < (uint32_t)KG_MAXGP ? (uint32_t)sh.wpos[wv][rem] : wv * 64 + nth_set_bit(KG_UNI64(sh.ball[wv]), rem));
+              const uint32_t pos = base + cpos;
+              const unsigned long long oe = KG_UNI64(ord_get(S, sh, P, ord_lds, ob, pos));
+              fast_eval_wave(P, S, sh, pc, lane, wave, (uint32_t)oe, pos, oe, need, &sh.ffeas[fpar], ord_lds, ob, nclaims, WT, wt, wt_last);
+            }
+            KG_SYNCW(1);
+          }
+          const uint32_t fm = KG_UNI(sh.ffeas[fpar]);
+          found = fm != 0;
+          if (found) {
+            win_g = (uint32_t)__builtin_ctz(fm);
+            endk_fast = KG_UNI(sh.rows[win_g].pad_);
+            fast_win = true;
+          }
+          KG_T(3);
+          lo += nrow;
+          continue;
+        }
+#endif
         // (the first survivor in order is the winner in most placements: a small first pass keeps the memory pipeline free)
         const uint32_t gcap = (lo == 0 && !STATS && GP > (uint32_t)KG_GP0) ? (uint32_t)KG_GP0 : GP;
         const uint32_t nrow = nsv - lo < gcap ? nsv - lo : gcap;
@@ -1143,13 +1462,13 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
                 const uint32_t tm = S.c_tmpl[c];
                 R.npods = (uint32_t)(oe >> 32); R.stamp = S.c_stamp[c];
                 R.c = c; R.tmpl = tm; R.reason = 0; R.pos = pos; R.tv = 0; R.ent_changed = 0; R.ent_dne_ok = 0; R.sp_changed = 0; R.thr_use = 0;
-                R.ok = ((P.tol_tmpl[sh.pc.vc.v.tolset] >> tm) & 1) && sh.pc.vc.v.host_claim_ok;
-                if (P.has_ports && (S.c_ports[c] & sh.pc.vc.hp_conf)) { R.ok = 0; R.reason = 2; }
+                R.ok = ((pc.tolw >> tm) & 1) && pc.vc.v.host_claim_ok;
+                if (P.has_ports && (S.c_ports[c] & pc.vc.hp_conf)) { R.ok = 0; R.reason = 2; }
               }
             }
             KG_ST(5);
           }
-          KG_SYNC();
+          KG_SYNCW(5);
           KG_T(3);
         }
         // merge the pod: one thread per requirement entry (first half of the workgroup), one per resource (second
@@ -1159,18 +1478,18 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
           const uint32_t half = (uint32_t)tid / (NT / 2), t2 = (uint32_t)tid % (NT / 2);
           const uint32_t gi = t2 / KG_MAXE, j = t2 % KG_MAXE;
           if (gi < nrow && sh.rows[gi].ok) {
-            if (half == 0) { if (j < sh.pc.vc.ne) row_merge_entry(P, sh, sh.rows[gi], j, fresh); }
-            else if (j < (uint32_t)P.R) row_merge_resource(P, sh, sh.rows[gi], (int)j, fresh);
+            if (half == 0) { if (j < pc.vc.ne) row_merge_entry(P, sh, pc, sh.rows[gi], j, fresh); }
+            else if (j < (uint32_t)P.R) row_merge_resource(P, sh, pc, sh.rows[gi], (int)j, fresh);
           }
           KG_ST(6);
         }
-        KG_SYNC();
-        if (KG_UNI(sh.pc.vc.nlist)) {
+        KG_SYNCW(5);
+        if (KG_UNI(pc.vc.nlist)) {
           KG_FOR_THREADS(tid, NT) {
             const uint32_t gi = (uint32_t)tid / TWP, w = (uint32_t)tid % TWP;
-            if (gi < nrow && w == 0 && sh.rows[gi].ok) row_topology(P, S, sh, sh.rows[gi]);
+            if (gi < nrow && w == 0 && sh.rows[gi].ok) row_topology(P, S, sh, pc, sh.rows[gi]);
           }
-          KG_SYNC();
+          KG_SYNCW(5);
         }
         KG_T(4);
         // instance-type filter: one thread per 64-type word; when the pass is small enough, two threads (in
@@ -1183,16 +1502,16 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
             Row& R = sh.rows[gi];
             if (STATS && half == 0) atomic_add_u32(&R.tv, (uint32_t)popc64(S.c_mask[(size_t)w * P.Cmax + R.c]));
             if (split) {
-              R.mw[half][w] = half == 0 ? row_word_a(P, S, sh, R, fresh, (int)w) : row_word_b(P, S, sh, R, fresh, (int)w);
+              R.mw[half][w] = half == 0 ? row_word_a(P, S, sh, pc, R, fresh, (int)w) : row_word_b(P, S, sh, pc, R, fresh, (int)w);
             } else {
-              const uint64_t m = row_word_a(P, S, sh, R, fresh, (int)w) & row_word_b(P, S, sh, R, fresh, (int)w);
+              const uint64_t m = row_word_a(P, S, sh, pc, R, fresh, (int)w) & row_word_b(P, S, sh, pc, R, fresh, (int)w);
               S.scratch[(size_t)w * P.Cmax + R.c] = m;
               if (m) atomic_or_u32(&sh.feas[par], 1u << gi);
             }
           }
           KG_ST(7);
         }
-        KG_SYNC();
+        KG_SYNCW(5);
         if (split) {
           KG_FOR_THREADS(tid, NT) {
             const uint32_t gi = (uint32_t)tid / TWP, w = (uint32_t)tid % TWP;
@@ -1203,7 +1522,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
               if (m) atomic_or_u32(&sh.feas[par], 1u << gi);
             }
           }
-          KG_SYNC();
+          KG_SYNCW(5);
         }
         if (P.tmpl_minv_mask != 0) {
           // InstanceTypes.SatisfiesMinValues on the candidate option masks
@@ -1214,7 +1533,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
               if (((P.tmpl_minv_mask >> R.tmpl) & 1) && !claim_minvalues_ok(P, S, R.tmpl, R.c)) atomic_or_u32(&sh.mvf[par], 1u << gi);
             }
           }
-          KG_SYNC();
+          KG_SYNCW(5);
         }
         KG_T(5);
         // ---- the first row in order whose option mask stays non-empty takes the pod (every thread reads the same words)
@@ -1264,7 +1583,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
           }
           KG_ST(8);
         }
-        KG_SYNC();
+        KG_SYNCW(5);
         KG_T(6);
         lo += nrow;
       }
@@ -1284,11 +1603,12 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     if (result != 0) {
       // ---- commit NodeClaim.Add: the merged row goes back to the claim, the option mask comes from scratch, the claim
       // moves to the front of the next pod-count group of the scan order (a new claim: to the end of the one-pod group)
+      KG_W(26);
       const bool fr = result == 2;
       const uint32_t nnew = nclaims + (fr ? 1u : 0u);
       const bool dst_lds = ord_lds && nnew <= (uint32_t)KG_ORD;
       const uint32_t wc = KG_UNI(sh.rows[win_g].c), wpos = KG_UNI(sh.rows[win_g].pos), wnp = KG_UNI(sh.rows[win_g].npods), wst = KG_UNI(sh.rows[win_g].stamp);
-      const uint32_t endk = KG_UNI(sh.endk);
+      const uint32_t endk = fast_win ? endk_fast : KG_UNI(sh.endk);
       KG_FOR_THREADS(tid, NT) {
         const Row& R = sh.rows[win_g];
         const uint32_t c = wc;
@@ -1300,17 +1620,17 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
           const int r = tid - (NT - KG_MAXR);
           if (r < P.R) {
             S.c_req[(size_t)r * P.Cmax + c] = R.req[r];
-            if (!fr && sh.pc.preq[r] != 0) S.c_head[(size_t)r * P.Cmax + c] -= sh.pc.preq[r];
+            if (!fr && pc.preq[r] != 0) S.c_head[(size_t)r * P.Cmax + c] -= pc.preq[r];
           }
         }
         if (tid == NT / 2) {
           if (fr) { S.c_npods[c] = 1; S.c_tmpl[c] = (uint16_t)R.tmpl; S.c_hstamp[c] = seq + 1; }
           else S.c_npods[c] = wnp + 1;
-          if (P.has_ports) S.c_ports[c] = (fr ? 0ull : S.c_ports[c]) | sh.pc.vc.hp_use;
+          if (P.has_ports) S.c_ports[c] = (fr ? 0ull : S.c_ports[c]) | pc.vc.hp_use;
           S.c_stamp[c] = seq + 1;
           S.pod_kind[pod_row(S, pod)] = 2;
           S.pod_index[pod_row(S, pod)] = (int32_t)c;
-          row_record_topology(P, S, sh, R);
+          row_record_topology(P, S, sh, pc, R);
         }
         // scan order -> the other buffer
         for (uint32_t p = tid; p < nclaims; p += NT) {
@@ -1324,7 +1644,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
         if (fr && tid == NT - 1) ord_set(S, sh, P, dst_lds, ob ^ 1, endk, (1ull << 32) | c);
         KG_ST(9);
       }
-      KG_SYNC();
+      KG_SYNCW(2);
       if (fr) {
         KG_FOR_THREADS(tid, NT) {
           // headroom of the new claim; subtractMax: charge the worst-case capacity of the remaining options against the limits
@@ -1345,7 +1665,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
             }
           }
         }
-        KG_SYNC();
+        KG_SYNCW(3);
       }
       last_c = wc; last_new = fr ? 1u : 0u;
       if (!fr) { last_npods = wnp; last_stamp = wst; }
@@ -1354,7 +1674,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
       continue;
     }
     // ---- Preferences.Relax + Queue.Push
-    const int32_t vnext = (int32_t)KG_UNI((uint32_t)sh.pc.vc.v.next);
+    const int32_t vnext = (int32_t)KG_UNI((uint32_t)pc.vc.v.next);
     KG_FOR_THREADS(tid, NT) {
       if (tid == 0) {
         S.pod_kind[pod_row(S, pod)] = 0;
@@ -1377,7 +1697,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     if (vnext >= 0) epoch += 1;  // lastLen = {} on a relaxed push
     // the pushed entry is the head when nothing else is queued: it was not there when the next entry was fetched
     if (qlen == 1) { have_next = false; ctx_ready = false; }
-    KG_SYNC();
+    KG_SYNCW(7);
     KG_T(9);
   }
   KG_FOR_THREADS(tid, NT) {
@@ -1387,8 +1707,16 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     }
   }
   KG_SYNC();
+#if KG_DEVICE_ONLY
+  if (WT && (threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) S.counters[64 + (threadIdx.x >> 6) * 32 + i] = wt[i];
+  }
+#endif
 #undef KG_T
 #undef KG_ST
+#undef KG_W
+#undef KG_SYNCW
 }
 
 }  // namespace kg
