@@ -353,6 +353,7 @@ typedef struct {
   double device_ms_total, host_compile_ms_total;
   uint64_t device_bytes_resident;
   uint64_t catalog_words_patched; /* 8-byte words of resident catalogs rewritten in place by kg_catalog_update_offerings */
+  uint64_t wave_solves;           /* kg_solve calls served by the single-wave kernel (batches without topology groups / existing nodes / minValues) */
 } kg_stats;
 
 typedef struct kg_ctx kg_ctx;

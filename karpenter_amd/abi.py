@@ -150,7 +150,7 @@ class CandidatesDesc(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("solves", C.c_uint64), ("pods", C.c_uint64), ("kernel_launches", C.c_uint64), ("device_ms_total", C.c_double),
-                ("host_compile_ms_total", C.c_double), ("device_bytes_resident", C.c_uint64), ("catalog_words_patched", C.c_uint64)]
+                ("host_compile_ms_total", C.c_double), ("device_bytes_resident", C.c_uint64), ("catalog_words_patched", C.c_uint64), ("wave_solves", C.c_uint64)]
 
 
 def _ptr(a):

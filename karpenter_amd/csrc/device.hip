@@ -5,6 +5,7 @@
 #include <string>
 
 #include "hal.hpp"
+#include "solve_wave.hpp"
 
 namespace kg {
 
@@ -116,6 +117,14 @@ __global__ void __launch_bounds__(NT) k_simulate(DevProblem Pin, const SimState*
   solve_block<NT>(P, S, sh, nqueue[blockIdx.x]);
 }
 
+// k_solve_wave: one WAVE = one Scheduler.Solve (solve_wave.hpp: batches without topology groups / existing nodes / minValues)
+__global__ void __launch_bounds__(64) k_solve_wave(DevProblem Pin, const SimState* sims, const uint32_t* nqueue) {
+  __shared__ Shared sh;
+  const DevProblem& P = Pin;
+  const SimState S = sims[blockIdx.x];
+  solve_wave(P, S, sh, nqueue[blockIdx.x]);
+}
+
 // k_sim_init: one workgroup per simulation copies the pristine state image into its slot and applies the patches
 __global__ void __launch_bounds__(256) k_sim_init(DevProblem P, SimBatch B) {
   sim_init_copy(B, blockIdx.x, threadIdx.x, blockDim.x);
@@ -191,6 +200,12 @@ void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const ui
   else if (block >= 512) hipLaunchKernelGGL((k_solve<512>), dim3(nsims), dim3(512), 0, 0, P, sims, nqueue);
   else hipLaunchKernelGGL((k_solve<256>), dim3(nsims), dim3(256), 0, 0, P, sims, nqueue);
   ck(hipGetLastError(), "solve launch");
+  *ms = t.stop();
+}
+void launch_solve_wave(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, float* ms) {
+  Timer t;
+  hipLaunchKernelGGL(k_solve_wave, dim3(nsims), dim3(64), 0, 0, P, sims, nqueue);
+  ck(hipGetLastError(), "solve (wave) launch");
   *ms = t.stop();
 }
 void launch_sim_init(const DevProblem& P, const SimBatch& B, float* ms) {

@@ -40,6 +40,9 @@ void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const ui
   }
   *ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
+void launch_solve_wave(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, float* ms) {
+  launch_solve(P, sims, nsims, nqueue, 256, ms, false);
+}
 void launch_sim_init(const DevProblem& P, const SimBatch& B, float* ms) {
   for (int i = 0; i < B.nsims; ++i) {
     for (uint32_t t = 0; t < 64; ++t) sim_init_copy(B, (uint32_t)i, t, 64);

@@ -281,6 +281,7 @@ struct Compiled {
   std::vector<uint8_t> state_image;
   size_t state_bytes = 0;
   uint32_t qcap = 0;
+  bool wave_ok = false;  // the single-wave solve applies (no topology groups, no existing nodes, no minValues, tables fit LDS)
   std::vector<uint32_t> queue_order, pod_variant0;  // pods in Queue order; initial variant of every pod
   // simulations: what every bound pod of the universe adds to the initial topology counts (it is taken out of the
   // simulations that reschedule it): gcount index g * 64 + d, or 0x80000000 | hcount index
@@ -1083,6 +1084,14 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   if (TWP > 256) throw Unsupported("more than 16384 instance types");
   D.tmpl_minv_mask = tmpl_minv_mask;
   D.has_ports = port_vocab.empty() ? 0 : 1;
+  {
+    uint32_t thr_total = 0;
+    for (int r = 0; r < R; ++r) thr_total += ((const uint32_t*)(CT.image.bytes.data() + CT.o_thr_n))[C.act_res[r]];
+    bool ok = !sim_mode && G == 0 && N == 0 && tmpl_minv_mask == 0 && TW <= KG_TWLDS && Ka <= KG_MAXKA && C.Wa <= 64 && thr_total <= (uint32_t)KG_THR_LDS &&
+              CT.n_zone_vals * CT.n_ct_vals <= (uint32_t)KG_OFFROWS;
+    for (int sp = 0; sp < nspec; ++sp) ok = ok && ktwv_n[C.spec_slot[sp]] <= KG_SPV;
+    C.wave_ok = ok;
+  }
   D.TWP = TWP; D.NV = NV; D.stats = (stats ? 1 : 0) | (ctx->collect_timers ? 2 : 0) | (ctx->no_fast_path ? 4 : 0) | (ctx->wave_timers ? 8 : 0);  // (DevProblem::stats bit 2 = no wave-local evaluation)
   for (int r = 0; r < R; ++r) {
     const uint32_t g = C.act_res[r];
@@ -1494,7 +1503,9 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
   auto t1 = std::chrono::steady_clock::now();
   float ms_pre = 0, ms_solve = 0;
   hal::launch_prepass(C->dp, C->pre, &ms_pre);
-  hal::launch_solve(C->dp, (const SimState*)C->sims_dev.ptr, 1, (const uint32_t*)((uint8_t*)C->state_dev.ptr + C->o_nqueue), ctx->block_threads, &ms_solve);
+  const uint32_t* nq_dev = (const uint32_t*)((uint8_t*)C->state_dev.ptr + C->o_nqueue);
+  if (C->wave_ok && !stats && !ctx->collect_timers && !ctx->wave_timers && !ctx->no_fast_path) { hal::launch_solve_wave(C->dp, (const SimState*)C->sims_dev.ptr, 1, nq_dev, &ms_solve); ctx->stats.wave_solves += 1; }
+  else hal::launch_solve(C->dp, (const SimState*)C->sims_dev.ptr, 1, nq_dev, ctx->block_threads, &ms_solve);
   ctx->stats.kernel_launches += 3;
   // ---- results
   const int P = C->P, Cmax = C->Cmax, TW = C->TW, R = C->R, Ka = C->Ka;

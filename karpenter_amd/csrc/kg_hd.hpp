@@ -20,6 +20,8 @@
 #define KG_OPAQUE64(x) ((void)0)
 #define KG_UNI(x) (x)
 #define KG_UNI64(x) (x)
+#define KG_UNIV(v) ((void)0)
+#define KG_UNIB(v) ((void)0)
 struct alignas(16) uint4 { uint32_t x, y, z, w; };
 namespace kg {
 inline void atomic_min_u32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
@@ -60,6 +62,8 @@ inline int ctz64(uint64_t x) { return __builtin_ctzll(x); }
 // so that it lives in a scalar register and steers scalar branches instead of exec-mask bookkeeping.
 #define KG_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #define KG_UNI64(x) kg::uni64((unsigned long long)(x))
+#define KG_UNIV(v) ((v) = KG_UNI(v))
+#define KG_UNIB(v) ((v) = KG_UNI((uint32_t)(v)) != 0)
 namespace kg {
 __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));

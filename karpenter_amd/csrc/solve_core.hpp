@@ -1091,39 +1091,9 @@ __device__ __forceinline__ void fast_eval_wave(const DevProblem& P, const SimSta
 }
 #endif
 
-// ------------------------------------------------------------------ one Solve by one workgroup
-// NT = threads in the workgroup.  `sh` lives in LDS.
-//
-// Control state (queue ring, claim count, stage, winner) is UNIFORM: every thread keeps its own copy in registers and
-// derives it from the same LDS / global words, so no phase exists only to let thread 0 decide and broadcast.  Variables
-// declared outside the KG_FOR_THREADS bodies are such uniform values (the emulation keeps one copy of them).
-//
-// Barrier discipline: an LDS word that steers uniform control flow is only ever written in a phase that is followed by
-// a barrier AND is at least one barrier after the last uniform read of it -- otherwise a fast wave overwrites it while
-// a slow wave has not branched yet, and the waves' barrier counts diverge.  Words written once per pass alternate
-// between two slots for that reason (feas, mvf, fresh_lim).
+// ------------------------------------------------------------------ small problem tables -> LDS (start of every solve)
 template <int NT>
-KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint32_t n_queue) {
-  const bool STATS = (P.stats & 1) != 0;
-  const bool TIMERS = (P.stats & 2) != 0;  // per-phase wall-clock ticks (100 MHz) of thread 0 into counters[8..]
-  unsigned long long t_mark = 0;
-#define KG_T(i) do { if (TIMERS) { KG_FOR_THREADS(tid, NT) { if (tid == 0) { const unsigned long long n_ = now_ticks(); if (t_mark) S.counters[8 + (i)] += n_ - t_mark; t_mark = n_; } } } } while (0)
-  // (inside a phase body: thread 0's own progress, counters[32 + k])
-#define KG_ST(k) do { if (TIMERS && tid == 0) { const unsigned long long n_ = now_ticks(); if (t_mark) S.counters[32 + (k)] += n_ - t_mark; t_mark = n_; } } while (0)
-  // per-wave cycle accounting (stats & 8): work / barrier wait of every phase kind, kept in registers, written at the end
-#if KG_DEVICE_ONLY
-  const bool WT = (P.stats & 8) != 0;
-  unsigned long long wt_last = 0, wt[32];
-#pragma unroll
-  for (int i = 0; i < 32; ++i) wt[i] = 0;
-#define KG_W(k) do { if (WT) { const unsigned long long n_ = clock64(); if (wt_last) wt[k] += n_ - wt_last; wt_last = n_; } } while (0)
-#else
-#define KG_W(k) ((void)0)
-#endif
-#define KG_SYNCW(ph) do { KG_W(2 * (ph)); KG_SYNC(); KG_W(2 * (ph) + 1); } while (0)
-  const uint32_t TWP = (uint32_t)P.TWP;      // threads per evaluation group (power of two >= max(TW, 16))
-  const uint32_t GP = (NT / TWP) < (uint32_t)KG_MAXGP ? (NT / TWP) : (uint32_t)KG_MAXGP;  // claims evaluated per pass
-  static_assert(NT % 64 == 0 && NT / 64 <= 16, "one ballot word per wave");
+KG_HD void stage_tables(const DevProblem& P, Shared& sh) {
   // ---- stage the small problem tables in LDS
   KG_FOR_THREADS(tid, NT) {
     if (tid < KG_MAXR) {
@@ -1176,6 +1146,42 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     }
     KG_SYNC();
   }
+}
+
+// ------------------------------------------------------------------ one Solve by one workgroup
+// NT = threads in the workgroup.  `sh` lives in LDS.
+//
+// Control state (queue ring, claim count, stage, winner) is UNIFORM: every thread keeps its own copy in registers and
+// derives it from the same LDS / global words, so no phase exists only to let thread 0 decide and broadcast.  Variables
+// declared outside the KG_FOR_THREADS bodies are such uniform values (the emulation keeps one copy of them).
+//
+// Barrier discipline: an LDS word that steers uniform control flow is only ever written in a phase that is followed by
+// a barrier AND is at least one barrier after the last uniform read of it -- otherwise a fast wave overwrites it while
+// a slow wave has not branched yet, and the waves' barrier counts diverge.  Words written once per pass alternate
+// between two slots for that reason (feas, mvf, fresh_lim).
+template <int NT>
+KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint32_t n_queue) {
+  const bool STATS = (P.stats & 1) != 0;
+  const bool TIMERS = (P.stats & 2) != 0;  // per-phase wall-clock ticks (100 MHz) of thread 0 into counters[8..]
+  unsigned long long t_mark = 0;
+#define KG_T(i) do { if (TIMERS) { KG_FOR_THREADS(tid, NT) { if (tid == 0) { const unsigned long long n_ = now_ticks(); if (t_mark) S.counters[8 + (i)] += n_ - t_mark; t_mark = n_; } } } } while (0)
+  // (inside a phase body: thread 0's own progress, counters[32 + k])
+#define KG_ST(k) do { if (TIMERS && tid == 0) { const unsigned long long n_ = now_ticks(); if (t_mark) S.counters[32 + (k)] += n_ - t_mark; t_mark = n_; } } while (0)
+  // per-wave cycle accounting (stats & 8): work / barrier wait of every phase kind, kept in registers, written at the end
+#if KG_DEVICE_ONLY
+  const bool WT = (P.stats & 8) != 0;
+  unsigned long long wt_last = 0, wt[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) wt[i] = 0;
+#define KG_W(k) do { if (WT) { const unsigned long long n_ = clock64(); if (wt_last) wt[k] += n_ - wt_last; wt_last = n_; } } while (0)
+#else
+#define KG_W(k) ((void)0)
+#endif
+#define KG_SYNCW(ph) do { KG_W(2 * (ph)); KG_SYNC(); KG_W(2 * (ph) + 1); } while (0)
+  const uint32_t TWP = (uint32_t)P.TWP;      // threads per evaluation group (power of two >= max(TW, 16))
+  const uint32_t GP = (NT / TWP) < (uint32_t)KG_MAXGP ? (NT / TWP) : (uint32_t)KG_MAXGP;  // claims evaluated per pass
+  static_assert(NT % 64 == 0 && NT / 64 <= 16, "one ballot word per wave");
+  stage_tables<NT>(P, sh);
   const uint32_t QCAP = S.qcap;
   // ---- uniform state of the Solve
   uint32_t qhead = 0, qlen = n_queue, epoch = 1;   // Queue ring; epoch/len implement lastLen

@@ -1,0 +1,480 @@
+// solve_wave.hpp -- Scheduler.Solve by ONE wavefront (device only).
+//
+// The workgroup-wide loop of solve_core.hpp pays a barrier, an LDS hand-over and the skew of four instruction streams at
+// every step of a placement.  When a Solve has no topology groups, no existing nodes and no minValues NodePool (a plain
+// provisioning batch: BASELINE config C2) nothing in a placement needs more than 64 lanes at a time, so one wave runs the
+// whole chain with no barrier at all:
+//   * prefilter: lane = scan position, 64 positions per step (headroom, option mask AND pod mask, toleration, host
+//     ports, and the pod's zone / capacity-type style entries against the claim's words); the ballot is the survivor
+//     list in scan order;
+//   * NodeClaim.Add on the survivors in order, the claim row distributed over the lanes (wave_add<> below: the same
+//     arithmetic as row_merge_entry_from / row_merge_resource / row_word_a / row_word_b of solve_core.hpp);
+//   * commit straight from registers; the scan order is rotated in place.
+// Same state layout, same results, same canonical order as solve_block (tests compare both with the oracle).
+#pragma once
+#include "solve_core.hpp"
+
+namespace kg {
+
+// Step 3-6 of NodeClaim.Add with the claim row in registers: lane a holds meta[a], lane i bits[i], lanes 8r the requests of
+// resource r, lane w word w of the option mask.  FRESH: the row is a NodeClaim just made from a template (every entry
+// counts as changed, template entries and the valid-type mask join the filter, hasOffering is always evaluated).
+// Returns "the option mask stays non-empty"; *compat = the requirement merge went through.
+template <bool FRESH>
+__device__ __forceinline__ bool wave_add(const DevProblem& P, const Shared& sh, const PodCtx& pc, uint32_t lane, uint32_t need, uint32_t tmpl, uint32_t& meta,
+                                         uint64_t& bits, int64_t& req, uint64_t& m, bool* compat) {
+  const uint32_t NR = (uint32_t)P.R, TW = (uint32_t)P.TW;
+  const uint32_t rg = lane >> 3;
+  uint4 pe4;
+  pe4.x = pe4.y = pe4.z = pe4.w = 0;
+  if (lane < KG_MAXE) pe4 = ((const uint4*)pc.vc.ent)[lane];
+  uint32_t spa = 0, spoff = 0;
+  if (lane < (uint32_t)P.nspec) { spa = sh.spec_slot[lane]; spoff = sh.aoff[spa]; }
+  uint32_t tn = 0, tbase = 0, toff = 0;
+  int64_t add = 0;
+  if (rg < NR) { tn = sh.a_thr_n[rg]; tbase = sh.thr_base[rg]; toff = sh.a_thr_off[rg]; add = pc.preq[rg]; }
+  const uint32_t ne = KG_UNI(pc.vc.ne);
+  bool ok = true;
+  // ---- step 3: the pod's requirement entries, one after the other (distinct keys)
+  uint32_t ent_changed = 0, ent_dne_ok = 0, sp_changed = 0, ent_ord = 0;
+  for (uint32_t j = 0; j < ne && ok; ++j) {
+    const uint32_t pm = rl32(pe4.y, j), ab = rl32(pe4.z, j), sw = rl32(pe4.w, j);
+    const uint32_t aoff = ab & 0xFFFF, pbits = ab >> 16, a = sw & 0xFF, w = (sw >> 16) & 0xFF, opc = sw >> 24;
+    const int spec = (int)(int8_t)((sw >> 8) & 0xFF);
+    if (spec < 0) ent_ord |= 1u << j;
+    const uint32_t cma = rl32(meta, a);
+    const bool inr = lane >= aoff && lane < aoff + w;
+    uint64_t y = 0;
+    if (pbits != 0xFFFF) { if (inr) { y = pc.vc.ebits[pbits + lane - aoff]; KG_OPAQUE64(y); } }
+    else if (inr) y = P.rs_bits[P.e_bits[rl32(pe4.x, j)] + lane - aoff];
+    if (!(cma & RM_PRESENT)) {
+      if (!((P.well_known_slots >> a) & 1) && !op_neg((int)opc)) { ok = false; break; }
+      if (op_neg((int)opc)) ent_dne_ok |= 1u << j;
+      ent_changed |= 1u << j;
+      if (spec >= 0) sp_changed |= 1u << spec;
+      if (inr) bits = y;
+      if (lane == a) meta = pm;
+      continue;
+    }
+    const bool xc = cma & RM_COMPL, yc = pm & RM_COMPL;
+    const uint32_t gt = rm_gt(cma) > rm_gt(pm) ? rm_gt(cma) : rm_gt(pm);
+    const uint32_t lt = min_nz(rm_lt(cma), rm_lt(pm));
+    const bool dne = gt && lt && P.gtval[P.bnd_off[a] + gt - 1] >= P.ltval[P.bnd_off[a] + lt - 1];
+    const uint32_t mm = (xc && yc && !dne) ? rm_make(true, gt, lt) : rm_make(false, 0, 0);
+    const uint64_t x = bits;
+    uint64_t r = x;
+    if (inr) {
+      r = dne ? 0 : ((xc && yc) ? (x | y) : (xc ? (y & ~x) : (yc ? (x & ~y) : (x & y))));
+      if (!dne && gt) r &= P.gtmask[P.bndmask_off[a] + (size_t)(gt - 1) * w + (lane - aoff)];
+      if (!dne && lt) r &= P.ltmask[P.bndmask_off[a] + (size_t)(lt - 1) * w + (lane - aoff)];
+    }
+    const bool anyb = __ballot(inr && r != 0) != 0, canyb = __ballot(inr && x != 0) != 0;
+    const bool chg = mm != cma || __ballot(inr && r != x) != 0;
+    if (inr) bits = r;
+    if (lane == a) meta = mm;
+    const int cop = opclass(xc, canyb);
+    const bool empty = !(mm & RM_COMPL) && !anyb;
+    if (empty && !(op_neg((int)opc) && op_neg(cop))) { ok = false; break; }
+    if (op_neg(opclass(mm & RM_COMPL, anyb))) ent_dne_ok |= 1u << j;
+    if (chg || FRESH) ent_changed |= 1u << j;
+    if (spec >= 0 && chg) sp_changed |= 1u << spec;
+  }
+  *compat = ok;
+  if (!ok) return false;
+  // ---- step 5: requests including the pod; every fit threshold at once, 8-ary search in the resource's lanes
+  const int64_t nr = req + add;
+  req = nr;
+  const bool ruse = rg < NR && (FRESH || ((need >> rg) & 1)) && nr > 0;
+  uint32_t tidx = 0;
+  {
+    uint32_t lo = 0;
+    const uint32_t j8 = lane & 7, sh8 = lane & 56u;
+    for (uint32_t stride = KG_UNI(sh.thr_stride0); stride; stride >>= 3) {
+      const uint32_t q = lo + j8 * stride;
+      bool f = true;
+      if (q < tn) f = sh.thr_val[tbase + q] >= nr;
+      const uint32_t gb = (uint32_t)(__ballot(f) >> sh8) & 0xFFu;
+      const uint32_t L = gb ? (uint32_t)__builtin_ctz(gb) : 8u;
+      if (stride == 1) lo = lo + L;
+      else if (L != 0) lo = lo + (L - 1) * stride + 1;
+    }
+    tidx = lo;
+  }
+  const unsigned long long useb = __ballot(ruse && (lane & 7) == 0);  // bit 8r: resource r decides
+  if (__ballot(ruse && tidx >= tn) != 0) return false;                // a request above every instance type
+  const uint32_t trow = toff + (tidx < tn ? tidx : 0);
+  // ---- step 6: the instance-type filter on lanes [0, TW)
+  const uint32_t w = lane < TW ? lane : 0;
+  uint64_t tmk[KG_MAXR];
+#pragma unroll
+  for (int r = 0; r < KG_MAXR; ++r) {
+    tmk[r] = ~0ull;
+    if ((useb >> (8 * r)) & 1) tmk[r] = P.thr_mask[(size_t)rl32(trow, 8 * r) * TW + w];
+  }
+  for (uint32_t em = ent_changed & ent_ord; em; em &= em - 1) {
+    const uint32_t j = (uint32_t)__builtin_ctz(em);
+    uint64_t f = pc.eam[j][w];
+    KG_OPAQUE64(f);
+    if ((ent_dne_ok >> j) & 1) f |= P.kU[(size_t)(rl32(pe4.w, j) & 0xFF) * TW + w];
+    m &= f;
+  }
+  if (FRESH) {
+    // template entries on ordinary keys (the merged operator class is the pod entry's when the pod shares the key)
+    const uint32_t trs = P.tmpl_rs[tmpl];
+    const uint32_t t0 = P.rs_off[trs], t1 = P.rs_off[trs + 1];
+    for (uint32_t e = t0; e < t1; ++e) {
+      const uint32_t a = P.e_slot[e];
+      if (sh.slot2spec[a] >= 0) continue;
+      uint64_t f = P.e_amask[(size_t)e * TW + w];
+      bool shared = false, dne_ok = false;
+      for (uint32_t j = 0; j < ne; ++j)
+        if ((rl32(pe4.w, j) & 0xFF) == a) { shared = true; dne_ok = (ent_dne_ok >> j) & 1; }
+      if (!shared) {
+        const uint64_t* tb = P.rs_bits + P.e_bits[e];
+        bool anyb = false;
+        for (int i = 0; i < sh.aw[a]; ++i) anyb |= tb[i] != 0;
+        dne_ok = op_neg(opclass(P.e_meta[e] & RM_COMPL, anyb));
+      }
+      if (dne_ok) f |= P.kU[(size_t)a * TW + w];
+      m &= f;
+    }
+    m &= P.valid_types[w];
+  }
+  if (sp_changed || FRESH) {
+    bool off_use = FRESH;
+    uint64_t zmask = ~0ull, ctmask = ~0ull;
+    for (int i = 0; i < P.nspec; ++i) {
+      const uint32_t a = rl32(spa, (uint32_t)i);
+      SReq sp;
+      sp.meta = rl32(meta, a);
+      const bool present = sp.meta & RM_PRESENT;
+      sp.word = present ? rl64(bits, rl32(spoff, (uint32_t)i)) : 0;
+      const bool changed = ((sp_changed >> i) & 1) || (FRESH && present);
+      const uint64_t hm = has_mask1(P, (int)a, sp);
+      if (changed && present) {
+        uint64_t f = P.kN[(size_t)a * TW + w];
+        if (op_neg(opclass(sp.meta & RM_COMPL, sp.word != 0))) f |= P.kU[(size_t)a * TW + w];
+        for (uint64_t q = hm & ((1ull << KG_SPV) - 1); q; q &= q - 1) { uint64_t g = sh.stw[i][ctz64(q)][w]; KG_OPAQUE64(g); f |= g; }
+        m &= f;
+      }
+      if (i == P.slot_zone || i == P.slot_ct || i == P.slot_zid) off_use = off_use || changed;
+      if (i == P.slot_zone) zmask &= hm;
+      if (i == P.slot_ct) ctmask = hm;
+      if (i == P.slot_zid) {
+        uint64_t zm = 0;
+        for (int z = 0; z < P.n_zone_vals; ++z) {
+          const uint8_t zid = P.zone_zid[z];
+          if (zid == 0xFF || ((hm >> zid) & 1)) zm |= 1ull << z;
+        }
+        zmask &= zm;
+      }
+    }
+    if (off_use) {
+      uint64_t f = 0;
+      for (int z = 0; z < P.n_zone_vals; ++z) {
+        if (!((zmask >> z) & 1)) continue;
+        for (int ct = 0; ct < P.n_ct_vals; ++ct)
+          if ((ctmask >> ct) & 1) { uint64_t g = sh.offm[z * P.n_ct_vals + ct][w]; KG_OPAQUE64(g); f |= g; }
+      }
+      m &= f;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < KG_MAXR; ++r) m &= tmk[r];
+  return __ballot(lane < TW && m != 0) != 0;
+}
+
+// max over the set types of mask (word w in lane w) of tab[type], for the types' table row `tab`
+__device__ __forceinline__ int64_t wave_max_over_mask(const int64_t* tab, uint64_t mask, uint32_t TW, uint32_t lane) {
+  int64_t mx = 0;
+  for (uint32_t w = 0; w < TW; ++w) {
+    const uint64_t mw = rl64(mask, w);
+    if ((mw >> lane) & 1) { const int64_t v = tab[w * 64 + lane]; mx = v > mx ? v : mx; }
+  }
+  return wave_max_i64(mx);
+}
+
+// scan order of the single-wave solve: one array, rotated in place (LDS while it fits, global memory beyond)
+constexpr uint32_t KG_WORD = 2 * KG_ORD;
+__device__ __forceinline__ unsigned long long word_get(const SimState& S, const Shared& sh, uint32_t p) {
+  if (p < KG_WORD) { unsigned long long v = (&sh.ord[0][0])[p]; KG_OPAQUE64(v); return v; }
+  return S.ordg[p];
+}
+__device__ __forceinline__ void word_set(const SimState& S, Shared& sh, uint32_t p, unsigned long long v) {
+  if (p < KG_WORD) (&sh.ord[0][0])[p] = v; else S.ordg[p] = v;
+}
+// end of the k-pod group: first position whose claim holds more than k pods (64-ary search)
+__device__ __forceinline__ uint32_t word_group_end(const SimState& S, const Shared& sh, uint32_t nclaims, uint32_t k, uint32_t lane) {
+  uint32_t stride = 1;
+  while ((unsigned long long)stride * 64 < nclaims) stride *= 64;
+  uint32_t lo = 0;
+  while (true) {
+    const unsigned long long q = (unsigned long long)lo + (unsigned long long)lane * stride;
+    bool f = true;
+    if (q < nclaims) f = (uint32_t)(word_get(S, sh, (uint32_t)q) >> 32) > k;
+    const unsigned long long b = __ballot(f);
+    const uint32_t L = b ? (uint32_t)(__ffsll(b) - 1) : 64u;
+    if (stride == 1) return lo + L;
+    if (L == 0) return lo;
+    lo = lo + (L - 1) * stride + 1;
+    stride /= 64;
+  }
+}
+
+// one Queue.Pop's worth of pod context by one wave
+__device__ __forceinline__ void ctx_fetch_wave(const DevProblem& P, PodCtx& nx, uint32_t lane, uint32_t pod, uint32_t variant) {
+  const uint64_t* src = (const uint64_t*)(P.vctx + variant);
+  uint64_t* dst = (uint64_t*)&nx.vc;
+  for (uint32_t i = lane; i < sizeof(VariantCtx) / 8; i += 64) dst[i] = src[i];
+  int64_t rq = 0;
+  if (lane < (uint32_t)P.R) rq = P.preq[(size_t)pod * P.R + lane];
+  if (lane < KG_MAXR) nx.preq[lane] = rq;
+  const unsigned long long nb = __ballot(rq != 0);
+  const VariantCtx* gv = P.vctx + variant;
+  if (lane == 0) { nx.need = (uint32_t)nb; nx.tolw = P.tol_tmpl[gv->v.tolset]; }
+  if (lane < KG_TWLDS) nx.podmask[lane] = lane < (uint32_t)P.TW ? P.podmask[(size_t)variant * P.TW + lane] : 0;
+  const uint32_t ne = gv->ne;
+  for (uint32_t i = lane; i < KG_MAXE * KG_TWLDS; i += 64) {
+    const uint32_t j = i / KG_TWLDS, w = i % KG_TWLDS;
+    if (j < ne && w < (uint32_t)P.TW) nx.eam[j][w] = P.e_amask[(size_t)gv->ent[j].e * P.TW + w];
+  }
+}
+
+// The whole Solve.  Preconditions (checked by the host before it picks this kernel): no topology groups, no existing
+// nodes, no minValues, TW <= KG_TWLDS, every table stages into LDS, visit counters off.
+__device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& S, Shared& sh, uint32_t n_queue) {
+  const uint32_t lane = threadIdx.x & 63;
+  stage_tables<64>(P, sh);
+  const uint32_t Ka = (uint32_t)P.Ka, Wa = (uint32_t)P.Wa, NR = (uint32_t)P.R, TW = (uint32_t)P.TW, NP = (uint32_t)P.NP;
+  const size_t Cmax = (size_t)P.Cmax;
+  const uint32_t rg = lane >> 3;
+  const uint32_t QCAP = S.qcap;
+  uint32_t qhead = 0, qlen = n_queue, epoch = 1, nclaims = 0, seq = 0, cur = 0;
+  uint32_t last_c = KG_NOIDX, last_npods = 0, last_stamp = 0, last_new = 0;
+  while (qlen != 0) {
+    // ---- Queue.Pop
+    const uint4 qv = ((const KG_GLOBAL uint4*)S.queue)[qhead];
+    const uint32_t pod = KG_UNI(qv.x), variant = KG_UNI(qv.y), qz = KG_UNI(qv.z), qw = KG_UNI(qv.w);
+    if (qz == epoch && qw == qlen) break;  // every remaining pod failed with the queue at this length
+    qhead = qhead + 1 == QCAP ? 0 : qhead + 1;
+    qlen -= 1;
+    cur ^= 1;
+    PodCtx& pcw = sh.pcb[cur];
+    ctx_fetch_wave(P, pcw, lane, pod, variant);
+    const PodCtx& pc = pcw;
+    const uint32_t need = KG_UNI(pc.need);
+    const uint64_t tolw = KG_UNI64(pc.tolw), hp_conf = P.has_ports ? KG_UNI64(pc.vc.hp_conf) : 0ull;
+    const bool hcok = KG_UNI(pc.vc.v.host_claim_ok) != 0;
+    const uint32_t ne = KG_UNI(pc.vc.ne);
+    // the pod's entries on 1-word ("special") keys, for the prefilter: a claim whose word on such a key is a plain set
+    // (In) disjoint from the pod's plain set can never take the pod
+    uint32_t sp_n = 0, sp_slot[2] = {0, 0}, sp_off[2] = {0, 0};
+    uint64_t sp_word[2] = {0, 0};
+    for (uint32_t j = 0; j < ne; ++j) {
+      const PodEntry pe = pc.vc.ent[j];
+      const int spec = (int)KG_UNI((uint32_t)(int)pe.spec);
+      const uint32_t pm = KG_UNI(pe.meta), pb = KG_UNI(pe.bits);
+      if (spec < 0 || (pm & RM_COMPL) || pb == 0xFFFF || sp_n >= 2) continue;
+      const uint64_t pw = KG_UNI64(pc.vc.ebits[pb]);
+      if (pw == 0) continue;  // (DoesNotExist: compatible with a claim that says DoesNotExist too)
+      sp_slot[sp_n] = KG_UNI(pe.slot); sp_off[sp_n] = KG_UNI(pe.aoff); sp_word[sp_n] = pw;
+      sp_n += 1;
+    }
+    last_c = KG_NOIDX; last_new = 0;
+    uint32_t reason = 0;
+    bool placed = false;
+    // ---- in-flight NodeClaims in scan order, 64 positions per step
+    for (uint32_t base = 0; base < nclaims && !placed; base += 64) {
+      const uint32_t pos = base + lane;
+      bool ok = false;
+      unsigned long long oe = 0;
+      if (pos < nclaims) {
+        oe = word_get(S, sh, pos);
+        const uint32_t c = (uint32_t)oe;
+        const uint32_t tm = S.c_tmpl[c];
+        int64_t hd[KG_MAXR];
+#pragma unroll
+        for (int r = 0; r < KG_MAXR; ++r) hd[r] = 0;
+#pragma unroll
+        for (int r = 0; r < KG_MAXR; ++r) if ((need >> r) & 1) hd[r] = S.c_head[(size_t)r * Cmax + c];
+        uint64_t mk[KG_TWLDS];
+#pragma unroll
+        for (int w = 0; w < KG_TWLDS; ++w) mk[w] = 0;
+#pragma unroll
+        for (int w = 0; w < KG_TWLDS; ++w) if (w < (int)TW) mk[w] = S.c_mask[(size_t)w * Cmax + c];
+        uint32_t smeta[2] = {0, 0};
+        uint64_t sword[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if ((uint32_t)k < sp_n) { smeta[k] = S.c_meta[(size_t)sp_slot[k] * Cmax + c]; sword[k] = S.c_bits[(size_t)sp_off[k] * Cmax + c]; }
+        uint64_t ports = 0;
+        if (P.has_ports) ports = S.c_ports[c];
+        uint64_t any = 0;
+#pragma unroll
+        for (int w = 0; w < KG_TWLDS; ++w) any |= mk[w] & pc.podmask[w];
+        ok = ((tolw >> tm) & 1) && hcok && any != 0 && !(ports & hp_conf);
+#pragma unroll
+        for (int r = 0; r < KG_MAXR; ++r) ok = ok && (!((need >> r) & 1) || hd[r] >= pc.preq[r]);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if ((uint32_t)k < sp_n && (smeta[k] & RM_PRESENT) && !(smeta[k] & RM_COMPL) && !(sword[k] & sp_word[k])) ok = false;
+      }
+      // ---- exact NodeClaim.Add on the survivors, in order
+      for (unsigned long long sv = __ballot(ok); sv && !placed; sv &= sv - 1) {
+        const uint32_t sl = (uint32_t)(__ffsll(sv) - 1);
+        const unsigned long long woe = rl64(oe, sl);
+        const uint32_t c = (uint32_t)woe, wnp = (uint32_t)(woe >> 32), wpos = base + sl;
+        uint32_t meta = 0;
+        uint64_t bits = 0, cm = 0;
+        int64_t req = 0;
+        if (lane < Ka) meta = S.c_meta[(size_t)lane * Cmax + c];
+        if (lane < Wa) bits = S.c_bits[(size_t)lane * Cmax + c];
+        if (rg < NR) req = S.c_req[(size_t)rg * Cmax + c];
+        if (lane < TW) cm = S.c_mask[(size_t)lane * Cmax + c];
+        const uint32_t tm_v = S.c_tmpl[c], stamp_v = S.c_stamp[c], hst_v = S.c_hstamp[c];
+        const uint32_t endk = word_group_end(S, sh, nclaims, wnp, lane);  // (LDS work under the row's round trip)
+        const uint32_t tm = KG_UNI(tm_v), stamp = KG_UNI(stamp_v), hst = KG_UNI(hst_v);
+        const int64_t req0 = req;
+        uint64_t m = cm;
+        bool compat = true;
+        const bool feasible = wave_add<false>(P, sh, pc, lane, need, tm, meta, bits, req, m, &compat);
+        if (!feasible) {
+          if (hst != stamp) {
+            // the prefilter let an infeasible claim through: recompute its headroom (its options changed since)
+            for (uint32_t r = 0; r < NR; ++r) {
+              const int64_t mx = wave_max_over_mask(P.alloc + (size_t)KG_UNI(sh.a_res[r]) * P.T, cm, TW, lane);
+              const int64_t rq = (int64_t)rl64((uint64_t)req0, 8 * r);
+              if (lane == 0) S.c_head[(size_t)r * Cmax + c] = mx - rq;
+            }
+            if (lane == 0) S.c_hstamp[c] = stamp;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          }
+          continue;
+        }
+        // ---- commit: merged row back to the claim; the claim moves to the end of its pod-count group (= the front of
+        // the next one)
+        if (lane < Ka) S.c_meta[(size_t)lane * Cmax + c] = meta;
+        if (lane < Wa) S.c_bits[(size_t)lane * Cmax + c] = bits;
+        if (lane < TW) S.c_mask[(size_t)lane * Cmax + c] = m;
+        if (rg < NR && (lane & 7) == 0) {
+          S.c_req[(size_t)rg * Cmax + c] = req;
+          const int64_t pq = pc.preq[rg];
+          if (pq != 0) S.c_head[(size_t)rg * Cmax + c] -= pq;
+        }
+        if (lane == 0) {
+          S.c_npods[c] = wnp + 1;
+          S.c_stamp[c] = seq + 1;
+          S.pod_kind[pod_row(S, pod)] = 2;
+          S.pod_index[pod_row(S, pod)] = (int32_t)c;
+          if (P.has_ports) S.c_ports[c] = S.c_ports[c] | pc.vc.hp_use;
+        }
+        for (uint32_t p0 = wpos; p0 + 1 < endk; p0 += 64) {
+          const uint32_t p = p0 + lane;
+          unsigned long long v = 0;
+          if (p + 1 < endk) v = word_get(S, sh, p + 1);
+          if (p + 1 < endk) word_set(S, sh, p, v);
+        }
+        if (lane == 0) word_set(S, sh, endk - 1, ((unsigned long long)(wnp + 1) << 32) | c);
+        last_c = c; last_new = 0; last_npods = wnp; last_stamp = stamp;
+        seq += 1;
+        placed = true;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the next placement's lanes read what these lanes wrote
+      }
+    }
+    if (placed) continue;
+    // ---- a new NodeClaim from each template in weight order
+    if (nclaims < (uint32_t)P.Cmax) {
+      const uint32_t c = nclaims;
+      for (uint32_t t = 0; t < NP && !placed; ++t) {
+        // filterByRemainingResources: types whose capacity fits what the NodePool's limits leave
+        uint64_t cm = 0;
+        if (lane < TW) {
+          cm = ~0ull;
+          if (lane == TW - 1 && (P.T & 63)) cm = (1ull << (P.T & 63)) - 1;
+          if (P.tmpl_has_limits[t]) {
+            for (uint32_t r = 0; r < NR; ++r) {
+              if (!P.tmpl_limit_res[(size_t)r * NP + t]) continue;
+              const int idx = thr_lookup_le(P.cthr_val + sh.a_cthr_off[r], (int)sh.a_cthr_n[r], S.remaining[(size_t)r * NP + t]);
+              if (idx < 0) cm = 0; else cm &= P.cthr_mask[((size_t)sh.a_cthr_off[r] + idx) * TW + lane];
+            }
+          }
+        }
+        if (__ballot(cm != 0) == 0) { reason |= 16u; continue; }  // all available instance types exceed limits
+        if (!((tolw >> t) & 1) || !hcok) { reason |= ((tolw >> t) & 1) ? 2u : 1u; continue; }
+        // NewNodeClaim: the template's requirements and daemon overhead
+        uint32_t meta = 0;
+        uint64_t bits = 0;
+        const uint32_t trs = P.tmpl_rs[t];
+        for (uint32_t e = P.rs_off[trs]; e < P.rs_off[trs + 1]; ++e) {
+          const uint32_t a = P.e_slot[e], off = sh.aoff[a], w = sh.aw[a];
+          if (lane == a) meta = P.e_meta[e];
+          if (lane >= off && lane < off + w) bits = P.rs_bits[P.e_bits[e] + lane - off];
+        }
+        int64_t req = 0;
+        if (rg < NR) req = P.tmpl_req[(size_t)rg * NP + t];
+        uint64_t m = cm;
+        bool compat = true;
+        const bool feasible = wave_add<true>(P, sh, pc, lane, need, t, meta, bits, req, m, &compat);
+        if (!feasible) { reason |= compat ? 8u : 2u; continue; }
+        // ---- commit the new claim: appended to the end of the one-pod group
+        if (lane < Ka) S.c_meta[(size_t)lane * Cmax + c] = meta;
+        if (lane < Wa) S.c_bits[(size_t)lane * Cmax + c] = bits;
+        if (lane < TW) S.c_mask[(size_t)lane * Cmax + c] = m;
+        for (uint32_t r = 0; r < NR; ++r) {
+          const int64_t mx = wave_max_over_mask(P.alloc + (size_t)KG_UNI(sh.a_res[r]) * P.T, m, TW, lane);
+          const int64_t rq = (int64_t)rl64((uint64_t)req, 8 * r);
+          if (lane == 0) { S.c_req[(size_t)r * Cmax + c] = rq; S.c_head[(size_t)r * Cmax + c] = mx - rq; }
+          // subtractMax: the worst-case capacity of the remaining options is charged against the limits
+          if (P.tmpl_has_limits[t] && P.tmpl_limit_res[(size_t)r * NP + t]) {
+            const int64_t cx = wave_max_over_mask(P.cap + (size_t)KG_UNI(sh.a_res[r]) * P.T, m, TW, lane);
+            if (lane == 0) S.remaining[(size_t)r * NP + t] -= cx;
+          }
+        }
+        if (lane == 0) {
+          S.c_npods[c] = 1; S.c_tmpl[c] = (uint16_t)t; S.c_hstamp[c] = seq + 1; S.c_stamp[c] = seq + 1;
+          S.pod_kind[pod_row(S, pod)] = 2;
+          S.pod_index[pod_row(S, pod)] = (int32_t)c;
+          if (P.has_ports) S.c_ports[c] = pc.vc.hp_use;
+        }
+        const uint32_t endk = word_group_end(S, sh, nclaims, 1, lane);
+        // shift [endk, nclaims) right by one, from the top
+        for (uint32_t hi = nclaims; hi > endk;) {
+          const uint32_t lo2 = hi - endk > 64 ? hi - 64 : endk;
+          const uint32_t p = lo2 + lane;
+          unsigned long long v = 0;
+          if (p < hi) v = word_get(S, sh, p);
+          if (p < hi) word_set(S, sh, p + 1, v);
+          hi = lo2;
+        }
+        if (lane == 0) word_set(S, sh, endk, (1ull << 32) | c);
+        last_c = c; last_new = 1;
+        nclaims += 1; seq += 1;
+        placed = true;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      }
+    }
+    if (placed) continue;
+    // ---- Preferences.Relax + Queue.Push
+    const int32_t vnext = (int32_t)KG_UNI((uint32_t)pc.vc.v.next);
+    if (lane == 0) {
+      S.pod_kind[pod_row(S, pod)] = 0;
+      S.pod_index[pod_row(S, pod)] = -1;
+      S.pod_reason[pod_row(S, pod)] = reason ? reason : 8;
+      uint4 qn;
+      qn.x = pod;
+      if (vnext >= 0) { qn.y = (uint32_t)vnext; qn.z = 0; qn.w = 0; S.header[1] += 1; }
+      else { qn.y = variant; qn.z = epoch; qn.w = qlen + 1; }
+      ((KG_GLOBAL uint4*)S.queue)[(qhead + qlen) % QCAP] = qn;
+    }
+    qlen += 1;
+    if (vnext >= 0) epoch += 1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);  // the pushed entry may be the next pop
+  }
+  if (lane == 0) {
+    S.header[0] = nclaims;
+    S.header[2] = last_c; S.header[3] = last_npods; S.header[4] = last_stamp; S.header[5] = last_new;
+  }
+}
+
+}  // namespace kg
