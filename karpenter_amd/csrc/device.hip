@@ -37,6 +37,14 @@ __global__ void __launch_bounds__(256) k_pod_mask(DevProblem P, PrepassTables X)
   X.podmask_out[i] = pod_mask_word(P, i / P.TW, (int)(i % P.TW));
 }
 
+// k_pod_ctx: pod variants -> contiguous pod-context images (one thread per 8-byte word; after k_type_filter / k_pod_mask)
+__global__ void __launch_bounds__(256) k_pod_ctx(DevProblem P, PrepassTables X) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t per = sizeof(PodCtx) / 8;
+  if (i >= (uint32_t)P.NV * per || P.TW > KG_TWLDS) return;
+  ((uint64_t*)X.pctx_out)[i] = pod_ctx_word(P, i / per, i % per);
+}
+
 // k_solve: one workgroup = one Scheduler.Solve (persistent over the whole pod queue)
 template <int NT>
 __global__ void __launch_bounds__(NT) k_solve(DevProblem Pin, const SimState* sims, const uint32_t* nqueue) {
@@ -183,6 +191,8 @@ void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms) {
   if (P.N > 0 && P.S > 0) hipLaunchKernelGGL(k_node_static, dim3((P.N + 255) / 256, P.S), dim3(256), 0, 0, P, X);
   const uint32_t pm = (uint32_t)P.NV * (uint32_t)P.TW;
   if (pm) hipLaunchKernelGGL(k_pod_mask, dim3((pm + 255) / 256), dim3(256), 0, 0, P, X);
+  const uint32_t pcw = (uint32_t)P.NV * (uint32_t)(sizeof(PodCtx) / 8);
+  if (pcw && X.pctx_out && P.TW <= KG_TWLDS) hipLaunchKernelGGL(k_pod_ctx, dim3((pcw + 255) / 256), dim3(256), 0, 0, P, X);
   ck(hipGetLastError(), "prepass launch");
   *ms = t.stop();
 }

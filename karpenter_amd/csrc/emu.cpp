@@ -26,6 +26,8 @@ void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms) {
   }
   for (int vi = 0; vi < P.NV; ++vi)
     for (int w = 0; w < P.TW; ++w) X.podmask_out[(size_t)vi * P.TW + w] = pod_mask_word(P, (uint32_t)vi, w);
+  if (X.pctx_out && P.TW <= KG_TWLDS)
+    for (uint32_t i = 0; i < (uint32_t)P.NV * (uint32_t)(sizeof(PodCtx) / 8); ++i) ((uint64_t*)X.pctx_out)[i] = pod_ctx_word(P, i / (sizeof(PodCtx) / 8), i % (sizeof(PodCtx) / 8));
   *ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 

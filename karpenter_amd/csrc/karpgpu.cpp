@@ -287,7 +287,7 @@ struct Compiled {
   // simulations that reschedule it): gcount index g * 64 + d, or 0x80000000 | hcount index
   std::vector<std::vector<uint32_t>> contrib;
   std::vector<uint64_t> gdom_univ;   // [G] domains registered from the NodePools / instance types alone
-  size_t o_nports, o_cports;
+  size_t o_nports, o_cports, o_cpre;
   size_t o_nreq, o_creq, o_chead, o_chstamp, o_cmask, o_cbits, o_cmeta, o_cnpods, o_ctmpl, o_order, o_remaining, o_gcount, o_gdom, o_gpos, o_hcount, o_hpos, o_queue,
       o_podkind, o_excl, o_podindex, o_podreason, o_scratch, o_ordg, o_header, o_counters, o_nqueue;
   ~Compiled() {
@@ -1066,7 +1066,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
                o_ktoff = A.add(ktwv_off), o_ktn = A.add(ktwv_n), o_vrank = A.add(vrank), o_bnd = A.add(bnd_off), o_gtval = A.add(gtval),
                o_ltval = A.add(ltval), o_gtmask = A.add(gtmask), o_ltmask = A.add(ltmask), o_bmo = A.add(bndmask_off), o_rsoff = A.add(rs_off),
                o_eslot = A.add(e_slot), o_emeta = A.add(e_meta), o_ebits = A.add(e_bits), o_rsbits = A.add(rs_bits),
-               o_amask = A.reserve((size_t)std::max(E, 1u) * TW * 8), o_vctx = A.add(vctx), o_podmask = A.reserve((size_t)std::max(NV, 1) * TW * 8), o_atab = A.reserve(5 * KG_MAXR * 4), o_pv0 = A.add(pod_variant0), o_preq = A.add(preq),
+               o_amask = A.reserve((size_t)std::max(E, 1u) * TW * 8), o_vctx = A.add(vctx), o_podmask = A.reserve((size_t)std::max(NV, 1) * TW * 8), o_pctx = A.reserve(sim_mode ? 8 : (size_t)std::max(NV, 1) * sizeof(PodCtx)), o_atab = A.reserve(5 * KG_MAXR * 4), o_pv0 = A.add(pod_variant0), o_preq = A.add(preq),
                o_queue0 = A.add(queue0), o_lists = A.add(lists), o_tmplrs = A.add(tmpl_rs), o_tmplreq = A.add(tmpl_req),
                o_thl = A.add(tmpl_has_limits), o_tl0 = A.add(tmpl_limits0), o_tlr = A.add(tmpl_limit_res), o_toltmpl = A.add(tol_tmpl),
                o_minvoff = A.add(tmpl_minv_off), o_minvslot = A.add(minv_slot), o_minvmin = A.add(minv_min), o_navail = A.add(navail),
@@ -1114,7 +1114,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   D.ltval = (const int64_t*)dptr(o_ltval); D.gtmask = (const uint64_t*)dptr(o_gtmask); D.ltmask = (const uint64_t*)dptr(o_ltmask);
   D.bndmask_off = (const uint32_t*)dptr(o_bmo); D.rs_off = (const uint32_t*)dptr(o_rsoff); D.e_slot = (const uint8_t*)dptr(o_eslot);
   D.e_meta = (const uint32_t*)dptr(o_emeta); D.e_bits = (const uint32_t*)dptr(o_ebits); D.rs_bits = (const uint64_t*)dptr(o_rsbits);
-  D.e_amask = (const uint64_t*)dptr(o_amask); D.vctx = (const VariantCtx*)dptr(o_vctx); D.podmask = (const uint64_t*)dptr(o_podmask); D.pod_variant0 = (const uint32_t*)dptr(o_pv0);
+  D.e_amask = (const uint64_t*)dptr(o_amask); D.vctx = (const VariantCtx*)dptr(o_vctx); D.podmask = (const uint64_t*)dptr(o_podmask); D.pctx = (const PodCtx*)dptr(o_pctx); D.pod_variant0 = (const uint32_t*)dptr(o_pv0);
   D.preq = (const int64_t*)dptr(o_preq); D.queue0 = (const uint32_t*)dptr(o_queue0); D.lists = (const ListEntry*)dptr(o_lists);
   D.tmpl_rs = (const uint32_t*)dptr(o_tmplrs); D.tmpl_req = (const int64_t*)dptr(o_tmplreq); D.tmpl_has_limits = (const uint8_t*)dptr(o_thl);
   D.tmpl_limits0 = (const int64_t*)dptr(o_tl0); D.tmpl_limit_res = (const uint8_t*)dptr(o_tlr); D.tol_tmpl = (const uint64_t*)dptr(o_toltmpl);
@@ -1127,7 +1127,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   D.ndom = (const uint16_t*)dptr(o_ndom); D.groups = (const Group*)dptr(o_groups); D.filters = (const uint32_t*)dptr(o_filters);
   PrepassTables& X = C.pre;
   X.E = E; X.nval = (const uint16_t*)dptr(o_nval); X.rs_host_meta = (const uint32_t*)dptr(o_rhm); X.rs_host_off = (const uint32_t*)dptr(o_rho);
-  X.rs_host_nodes = (const uint32_t*)dptr(o_rhn); X.e_amask_out = (uint64_t*)dptr(o_amask); X.nlab_out = (uint64_t*)dptr(o_nlab); X.podmask_out = (uint64_t*)dptr(o_podmask);
+  X.rs_host_nodes = (const uint32_t*)dptr(o_rhn); X.e_amask_out = (uint64_t*)dptr(o_amask); X.nlab_out = (uint64_t*)dptr(o_nlab); X.podmask_out = (uint64_t*)dptr(o_podmask); X.pctx_out = sim_mode ? nullptr : (PodCtx*)dptr(o_pctx);
 
   // ---- simulation state image
   Arena SA;
@@ -1137,6 +1137,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   C.o_nreq = SA.add(nreq0);
   C.o_nports = SA.add(nports0);
   C.o_cports = SA.reserve((size_t)Cmax * 8);
+  C.o_cpre = SA.reserve(sim_mode ? 8 : (size_t)Cmax * 64);
   C.o_creq = SA.reserve((size_t)std::max(R, 1) * Cmax * 8);
   C.o_chead = SA.reserve((size_t)std::max(R, 1) * Cmax * 8);
   C.o_chstamp = SA.reserve((size_t)Cmax * 4);
@@ -1184,7 +1185,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
 static SimState sim_at(const Compiled& C, uint8_t* base) {
   auto sptr = [&](size_t off) { return base + off; };
   SimState St{};
-  St.nports = (uint64_t*)sptr(C.o_nports); St.c_ports = (uint64_t*)sptr(C.o_cports);
+  St.nports = (uint64_t*)sptr(C.o_nports); St.c_ports = (uint64_t*)sptr(C.o_cports); St.c_pre = (uint64_t*)sptr(C.o_cpre);
   St.nreq = (int64_t*)sptr(C.o_nreq); St.c_req = (int64_t*)sptr(C.o_creq); St.c_head = (int64_t*)sptr(C.o_chead); St.c_hstamp = (uint32_t*)sptr(C.o_chstamp); St.c_mask = (uint64_t*)sptr(C.o_cmask); St.c_bits = (uint64_t*)sptr(C.o_cbits);
   St.c_meta = (uint32_t*)sptr(C.o_cmeta); St.c_npods = (uint32_t*)sptr(C.o_cnpods); St.c_tmpl = (uint16_t*)sptr(C.o_ctmpl); St.c_stamp = (uint32_t*)sptr(C.o_order);
   St.remaining = (int64_t*)sptr(C.o_remaining); St.gcount = (int32_t*)sptr(C.o_gcount); St.gdom = (uint64_t*)sptr(C.o_gdom); St.gpos = (uint64_t*)sptr(C.o_gpos);
@@ -1504,7 +1505,8 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
   float ms_pre = 0, ms_solve = 0;
   hal::launch_prepass(C->dp, C->pre, &ms_pre);
   const uint32_t* nq_dev = (const uint32_t*)((uint8_t*)C->state_dev.ptr + C->o_nqueue);
-  if (C->wave_ok && !stats && !ctx->collect_timers && !ctx->wave_timers && !ctx->no_fast_path) { hal::launch_solve_wave(C->dp, (const SimState*)C->sims_dev.ptr, 1, nq_dev, &ms_solve); ctx->stats.wave_solves += 1; }
+  const bool use_wave = C->wave_ok && !stats && !ctx->collect_timers && !ctx->no_fast_path;
+  if (use_wave) { hal::launch_solve_wave(C->dp, (const SimState*)C->sims_dev.ptr, 1, nq_dev, &ms_solve); ctx->stats.wave_solves += 1; }
   else hal::launch_solve(C->dp, (const SimState*)C->sims_dev.ptr, 1, nq_dev, ctx->block_threads, &ms_solve);
   ctx->stats.kernel_launches += 3;
   // ---- results
@@ -1536,7 +1538,12 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
     fprintf(stderr, "[kg timers] survivors %llu rounds %llu false_pos %llu passes %llu\n", (unsigned long long)counters[20],
             (unsigned long long)counters[21], (unsigned long long)counters[22], (unsigned long long)counters[23]);
   }
-  if (ctx->wave_timers) {
+  if (ctx->wave_timers && use_wave) {
+    static const char* sec[] = {"pop + pod context", "prefilter", "row load + group end", "NodeClaim.Add", "commit", "refresh after a false survivor", "new NodeClaim", "loop back"};
+    for (int k = 0; k < 8; ++k) fprintf(stderr, "[kg wave] %-32s %9.0f kcycles\n", sec[k], counters[64 + k] / 1e3);
+    fprintf(stderr, "[kg wave] prefilter steps %llu, survivors %llu, exact evaluations %llu\n", (unsigned long long)counters[72], (unsigned long long)counters[73],
+            (unsigned long long)counters[74]);
+  } else if (ctx->wave_timers) {
     static const char* ph[] = {"prefilter", "wave-local Add", "commit", "fresh commit", "fresh setup", "workgroup Add", "nodes", "relax / ctx"};
     for (int k = 0; k < 8; ++k) {
       fprintf(stderr, "[kg waves] %-15s work / wait kcycles:", ph[k]);

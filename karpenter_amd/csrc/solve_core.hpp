@@ -153,6 +153,7 @@ struct DevProblem {
   // variants / pods
   const VariantCtx* vctx;       // [NV]
   const uint64_t* podmask;      // [NV][TW] k_pod_mask output: types the pod's own requirements can ever accept
+  const struct PodCtx* pctx;    // [NV] k_pod_ctx output: everything a Queue.Pop needs of the variant, contiguous (requests left zero)
   const uint32_t* pod_variant0; // [P]
   const int64_t* preq;          // [P][R]
   const uint32_t* queue0;       // [P] pods in Queue order
@@ -191,6 +192,7 @@ struct SimState {
   KG_GLOBAL int64_t* nreq;      // [R][N]
   KG_GLOBAL uint64_t* nports;   // [N] host-port ids reserved on the node (bit per entry of the solve's port vocabulary)
   KG_GLOBAL uint64_t* c_ports;  // [Cmax] ... on the NodeClaim
+  KG_GLOBAL uint64_t* c_pre;    // [Cmax][8] prefilter records of the single-wave solve (solve_wave.hpp)
   KG_GLOBAL int64_t* c_req;     // [R][Cmax]
   KG_GLOBAL int64_t* c_head;    // [R][Cmax] upper bound of what the claim can still take: max allocatable over its options - c_req
   KG_GLOBAL uint64_t* c_mask;   // [TW][Cmax]
@@ -1851,6 +1853,7 @@ struct PrepassTables {
   uint64_t* e_amask_out;       // [E][TW]
   uint64_t* nlab_out;          // [S][NW]
   uint64_t* podmask_out;       // [NV][TW]
+  struct PodCtx* pctx_out;     // [NV]
 };
 
 KG_HD bool entry_has(const DevProblem& P, uint32_t e, int a, uint32_t v) {
@@ -1911,6 +1914,21 @@ KG_HD uint64_t pod_mask_word(const DevProblem& P, uint32_t vi, int w) {
       if ((ctmask >> ct) & 1) f |= P.offmask[((size_t)z * 4 + ct) * P.TW + w];
   }
   return m & f;
+}
+
+// word i of the contiguous pod-context image of variant vi (k_pod_ctx): the variant's precompiled record, its toleration
+// word, its own type mask and the type masks of its requirement entries, laid out as struct PodCtx (requests stay zero)
+KG_HD uint64_t pod_ctx_word(const DevProblem& P, uint32_t vi, uint32_t i) {
+  const uint32_t o_tolw = offsetof(PodCtx, tolw) / 8, o_vc = offsetof(PodCtx, vc) / 8, o_pm = offsetof(PodCtx, podmask) / 8, o_eam = offsetof(PodCtx, eam) / 8;
+  const VariantCtx& vc = P.vctx[vi];
+  if (i == o_tolw) return P.tol_tmpl[vc.v.tolset];
+  if (i >= o_vc && i < o_vc + sizeof(VariantCtx) / 8) return ((const uint64_t*)&vc)[i - o_vc];
+  if (i >= o_pm && i < o_pm + KG_TWLDS) return (int)(i - o_pm) < P.TW ? P.podmask[(size_t)vi * P.TW + (i - o_pm)] : 0;
+  if (i >= o_eam && i < o_eam + KG_MAXE * KG_TWLDS) {
+    const uint32_t j = (i - o_eam) / KG_TWLDS, w = (i - o_eam) % KG_TWLDS;
+    return (j < vc.ne && (int)w < P.TW) ? P.e_amask[(size_t)vc.ent[j].e * P.TW + w] : 0;
+  }
+  return 0;
 }
 
 // Requirements.Compatible(node labels + hostname, requirement set s) with no undefined-label allowance

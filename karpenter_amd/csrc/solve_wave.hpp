@@ -107,10 +107,9 @@ __device__ __forceinline__ bool wave_add(const DevProblem& P, const Shared& sh, 
   const uint32_t w = lane < TW ? lane : 0;
   uint64_t tmk[KG_MAXR];
 #pragma unroll
-  for (int r = 0; r < KG_MAXR; ++r) {
-    tmk[r] = ~0ull;
-    if ((useb >> (8 * r)) & 1) tmk[r] = P.thr_mask[(size_t)rl32(trow, 8 * r) * TW + w];
-  }
+  for (int r = 0; r < KG_MAXR; ++r) tmk[r] = P.thr_mask[(size_t)rl32(trow, 8 * r) * TW + w];  // (unconditional: one round trip; row 0 for unused lanes)
+#pragma unroll
+  for (int r = 0; r < KG_MAXR; ++r) tmk[r] = ((useb >> (8 * r)) & 1) ? tmk[r] : ~0ull;
   for (uint32_t em = ent_changed & ent_ord; em; em &= em - 1) {
     const uint32_t j = (uint32_t)__builtin_ctz(em);
     uint64_t f = pc.eam[j][w];
@@ -194,6 +193,30 @@ __device__ __forceinline__ int64_t wave_max_over_mask(const int64_t* tab, uint64
   return wave_max_i64(mx);
 }
 
+// Prefilter record of a NodeClaim (SimState::c_pre, 64 bytes = one cache line per claim, written at every commit):
+//   [0..3] headroom of active resources 0..3 (upper bound of what the claim can still take)
+//   [4]    type signature: bit b = some remaining instance type in bucket b (types [b << sh, (b + 1) << sh))
+//   [5][6] the claim's allowed values on the zone / capacity-type keys when they are plain non-empty sets, else all ones
+//   [7]    template
+// A pod can only land on a claim whose record passes all of: headroom >= requests, signature AND the pod's signature,
+// zone / capacity-type words AND the pod's, toleration of the template -- each one a necessary condition of NodeClaim.Add.
+constexpr int KG_PRE_WORDS = 8;
+__device__ __forceinline__ uint32_t sig_shift(uint32_t TW) { uint32_t sh = 0; while ((1u << sh) < TW) ++sh; return sh; }
+// bit b of the result = mask (word w in lane w) has a type in bucket b
+__device__ __forceinline__ uint64_t wave_signature(uint64_t mask, uint32_t sh, uint32_t lane) {
+  const uint32_t per = 6 - sh;                       // buckets per 64-type word = 1 << per
+  const uint32_t wi = lane >> per;                   // word that holds bucket `lane`
+  const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)mask, (int)wi, 64), hi = (uint32_t)__shfl((int)(uint32_t)(mask >> 32), (int)wi, 64);
+  const uint64_t word = ((uint64_t)hi << 32) | lo;
+  const uint32_t width = 1u << sh;
+  const uint64_t field = (word >> ((lane & ((1u << per) - 1)) << sh)) & (width >= 64 ? ~0ull : ((1ull << width) - 1));
+  return __ballot(field != 0);
+}
+// allowed-values word of a 1-word requirement for the record: the set itself when it is a plain non-empty set
+__device__ __forceinline__ uint64_t plain_set_or_all(uint32_t meta, uint64_t word) {
+  return ((meta & (RM_PRESENT | RM_COMPL)) == RM_PRESENT && word != 0) ? word : ~0ull;
+}
+
 // scan order of the single-wave solve: one array, rotated in place (LDS while it fits, global memory beyond)
 constexpr uint32_t KG_WORD = 2 * KG_ORD;
 __device__ __forceinline__ unsigned long long word_get(const SimState& S, const Shared& sh, uint32_t p) {
@@ -240,49 +263,101 @@ __device__ __forceinline__ void ctx_fetch_wave(const DevProblem& P, PodCtx& nx, 
   }
 }
 
+// the same from the contiguous image k_pod_ctx built (one level of loads)
+__device__ __forceinline__ void ctx_fetch_image(const DevProblem& P, PodCtx& nx, uint32_t lane, uint32_t pod, uint32_t variant) {
+  const uint64_t* img = (const uint64_t*)(P.pctx + variant);
+  uint64_t* dst = (uint64_t*)&nx;
+  int64_t rq = 0;
+  if (lane < (uint32_t)P.R) rq = P.preq[(size_t)pod * P.R + lane];
+  const unsigned long long nb = __ballot(rq != 0);
+  for (uint32_t i = lane; i < sizeof(PodCtx) / 8; i += 64) {
+    uint64_t v = img[i];
+    if (i < KG_MAXR) v = (uint64_t)rq;
+    if (i == KG_MAXR) v = (uint64_t)(uint32_t)nb;
+    dst[i] = v;
+  }
+}
+
 // The whole Solve.  Preconditions (checked by the host before it picks this kernel): no topology groups, no existing
 // nodes, no minValues, TW <= KG_TWLDS, every table stages into LDS, visit counters off.
 __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& S, Shared& sh, uint32_t n_queue) {
   const uint32_t lane = threadIdx.x & 63;
+  // cycle accounting per section of a placement (stats & 8; debug): registers, written once at the end
+  const bool WT = (P.stats & 8) != 0;
+  unsigned long long wt_last = 0, wt[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) wt[i] = 0;
+#define KG_W(k) do { if (WT) { const unsigned long long n_ = clock64(); if (wt_last) wt[k] += n_ - wt_last; wt_last = n_; } } while (0)
   stage_tables<64>(P, sh);
   const uint32_t Ka = (uint32_t)P.Ka, Wa = (uint32_t)P.Wa, NR = (uint32_t)P.R, TW = (uint32_t)P.TW, NP = (uint32_t)P.NP;
   const size_t Cmax = (size_t)P.Cmax;
   const uint32_t rg = lane >> 3;
+  const uint32_t sgsh = sig_shift(TW);
+  const int zslot = P.slot_zone >= 0 ? (int)sh.spec_slot[P.slot_zone] : -1, cslot = P.slot_ct >= 0 ? (int)sh.spec_slot[P.slot_ct] : -1;
+  const uint32_t zoff = zslot >= 0 ? (uint32_t)sh.aoff[zslot] : 0, coff = cslot >= 0 ? (uint32_t)sh.aoff[cslot] : 0;
   const uint32_t QCAP = S.qcap;
   uint32_t qhead = 0, qlen = n_queue, epoch = 1, nclaims = 0, seq = 0, cur = 0;
   uint32_t last_c = KG_NOIDX, last_npods = 0, last_stamp = 0, last_new = 0;
+  bool have_ctx = false, have_q2 = false;
+  uint32_t nq_pod = 0, nq_variant = 0, nq_z = 0, nq_w = 0;
+  uint4 q2;
+  q2.x = q2.y = q2.z = q2.w = 0;
   while (qlen != 0) {
     // ---- Queue.Pop
-    const uint4 qv = ((const KG_GLOBAL uint4*)S.queue)[qhead];
+    KG_W(7);
+    // (the head's entry and context were fetched during the previous placement unless the queue was too short then)
+    uint4 qv;
+    if (have_ctx) { qv.x = nq_pod; qv.y = nq_variant; qv.z = nq_z; qv.w = nq_w; }
+    else qv = ((const KG_GLOBAL uint4*)S.queue)[qhead];
     const uint32_t pod = KG_UNI(qv.x), variant = KG_UNI(qv.y), qz = KG_UNI(qv.z), qw = KG_UNI(qv.w);
     if (qz == epoch && qw == qlen) break;  // every remaining pod failed with the queue at this length
     qhead = qhead + 1 == QCAP ? 0 : qhead + 1;
     qlen -= 1;
     cur ^= 1;
-    PodCtx& pcw = sh.pcb[cur];
-    ctx_fetch_wave(P, pcw, lane, pod, variant);
-    const PodCtx& pc = pcw;
+    if (!have_ctx) ctx_fetch_image(P, sh.pcb[cur], lane, pod, variant);
+    const PodCtx& pc = sh.pcb[cur];
+    // ---- start on the next pod: its queue entry (loaded one placement ago, or now), its context image and requests go to
+    // registers now and to the other context buffer when this placement is over; the entry after it is requested as well
+    const bool next_ok = qlen >= 1;
+    uint32_t n_pod = 0, n_variant = 0, n_z = 0, n_w = 0;
+    uint64_t iw[4] = {0, 0, 0, 0};
+    int64_t n_rq = 0;
+    if (next_ok) {
+      uint4 ne4 = q2;
+      if (!have_q2) ne4 = ((const KG_GLOBAL uint4*)S.queue)[qhead];
+      n_pod = KG_UNI(ne4.x); n_variant = KG_UNI(ne4.y); n_z = KG_UNI(ne4.z); n_w = KG_UNI(ne4.w);
+      const uint64_t* img = (const uint64_t*)(P.pctx + n_variant);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const uint32_t i = lane + 64 * k; iw[k] = img[i < sizeof(PodCtx) / 8 ? i : 0]; }
+      if (lane < NR) n_rq = P.preq[(size_t)n_pod * NR + lane];
+      have_q2 = qlen >= 2;
+      if (have_q2) q2 = ((const KG_GLOBAL uint4*)S.queue)[qhead + 1 == QCAP ? 0 : qhead + 1];
+    } else {
+      have_q2 = false;
+    }
     const uint32_t need = KG_UNI(pc.need);
     const uint64_t tolw = KG_UNI64(pc.tolw), hp_conf = P.has_ports ? KG_UNI64(pc.vc.hp_conf) : 0ull;
     const bool hcok = KG_UNI(pc.vc.v.host_claim_ok) != 0;
     const uint32_t ne = KG_UNI(pc.vc.ne);
-    // the pod's entries on 1-word ("special") keys, for the prefilter: a claim whose word on such a key is a plain set
-    // (In) disjoint from the pod's plain set can never take the pod
-    uint32_t sp_n = 0, sp_slot[2] = {0, 0}, sp_off[2] = {0, 0};
-    uint64_t sp_word[2] = {0, 0};
+    // the pod's side of the prefilter record test
+    uint64_t pzone = ~0ull, pct = ~0ull;
     for (uint32_t j = 0; j < ne; ++j) {
       const PodEntry pe = pc.vc.ent[j];
       const int spec = (int)KG_UNI((uint32_t)(int)pe.spec);
       const uint32_t pm = KG_UNI(pe.meta), pb = KG_UNI(pe.bits);
-      if (spec < 0 || (pm & RM_COMPL) || pb == 0xFFFF || sp_n >= 2) continue;
-      const uint64_t pw = KG_UNI64(pc.vc.ebits[pb]);
-      if (pw == 0) continue;  // (DoesNotExist: compatible with a claim that says DoesNotExist too)
-      sp_slot[sp_n] = KG_UNI(pe.slot); sp_off[sp_n] = KG_UNI(pe.aoff); sp_word[sp_n] = pw;
-      sp_n += 1;
+      if (spec < 0 || pb == 0xFFFF || (spec != P.slot_zone && spec != P.slot_ct)) continue;
+      const uint64_t pw = plain_set_or_all(pm, KG_UNI64(pc.vc.ebits[pb]));
+      if (spec == P.slot_zone) pzone = pw; else pct = pw;
     }
+    const uint64_t psig = wave_signature(lane < TW ? pc.podmask[lane < KG_TWLDS ? lane : 0] : 0ull, sgsh, lane);
     last_c = KG_NOIDX; last_new = 0;
     uint32_t reason = 0;
     bool placed = false;
+    KG_W(0);
+    // the pod's side of the prefilter, in vector registers (the same value in every lane)
+    int64_t prq[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) prq[r] = pc.preq[r];
     // ---- in-flight NodeClaims in scan order, 64 positions per step
     for (uint32_t base = 0; base < nclaims && !placed; base += 64) {
       const uint32_t pos = base + lane;
@@ -291,36 +366,34 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
       if (pos < nclaims) {
         oe = word_get(S, sh, pos);
         const uint32_t c = (uint32_t)oe;
-        const uint32_t tm = S.c_tmpl[c];
-        int64_t hd[KG_MAXR];
+        // the claim's prefilter record: one cache line, four 16-byte loads, one round trip
+        const KG_GLOBAL uint4* rec = (const KG_GLOBAL uint4*)(S.c_pre + (size_t)c * KG_PRE_WORDS);
+        const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+        const int64_t h0 = (int64_t)(((uint64_t)q0.y << 32) | q0.x), h1 = (int64_t)(((uint64_t)q0.w << 32) | q0.z);
+        const int64_t h2 = (int64_t)(((uint64_t)q1.y << 32) | q1.x), h3 = (int64_t)(((uint64_t)q1.w << 32) | q1.z);
+        const uint64_t csig = ((uint64_t)q2.y << 32) | q2.x, czone = ((uint64_t)q2.w << 32) | q2.z, cct = ((uint64_t)q3.y << 32) | q3.x;
+        const uint32_t tm = q3.z;
+        uint32_t bad = (uint32_t)(((tolw >> tm) & 1) == 0) | (uint32_t)((csig & psig) == 0) | (uint32_t)((czone & pzone) == 0) | (uint32_t)((cct & pct) == 0);
+        bad |= ((uint32_t)(h0 < prq[0]) & need) | ((uint32_t)(h1 < prq[1]) & (need >> 1)) | ((uint32_t)(h2 < prq[2]) & (need >> 2)) | ((uint32_t)(h3 < prq[3]) & (need >> 3));
+        bad &= 1u;
+        if (P.has_ports) bad |= (uint32_t)((S.c_ports[c] & hp_conf) != 0);
+        ok = hcok && bad == 0;
+        if (ok) {
+          // second stage, for the few claims the record lets through: the exact option mask AND the pod's mask
+          uint64_t mk[KG_TWLDS];
 #pragma unroll
-        for (int r = 0; r < KG_MAXR; ++r) hd[r] = 0;
+          for (int w = 0; w < KG_TWLDS; ++w) mk[w] = S.c_mask[(size_t)((uint32_t)w < TW ? (uint32_t)w : TW - 1) * Cmax + c];
+          uint64_t any = 0;
 #pragma unroll
-        for (int r = 0; r < KG_MAXR; ++r) if ((need >> r) & 1) hd[r] = S.c_head[(size_t)r * Cmax + c];
-        uint64_t mk[KG_TWLDS];
-#pragma unroll
-        for (int w = 0; w < KG_TWLDS; ++w) mk[w] = 0;
-#pragma unroll
-        for (int w = 0; w < KG_TWLDS; ++w) if (w < (int)TW) mk[w] = S.c_mask[(size_t)w * Cmax + c];
-        uint32_t smeta[2] = {0, 0};
-        uint64_t sword[2] = {0, 0};
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-          if ((uint32_t)k < sp_n) { smeta[k] = S.c_meta[(size_t)sp_slot[k] * Cmax + c]; sword[k] = S.c_bits[(size_t)sp_off[k] * Cmax + c]; }
-        uint64_t ports = 0;
-        if (P.has_ports) ports = S.c_ports[c];
-        uint64_t any = 0;
-#pragma unroll
-        for (int w = 0; w < KG_TWLDS; ++w) any |= mk[w] & pc.podmask[w];
-        ok = ((tolw >> tm) & 1) && hcok && any != 0 && !(ports & hp_conf);
-#pragma unroll
-        for (int r = 0; r < KG_MAXR; ++r) ok = ok && (!((need >> r) & 1) || hd[r] >= pc.preq[r]);
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-          if ((uint32_t)k < sp_n && (smeta[k] & RM_PRESENT) && !(smeta[k] & RM_COMPL) && !(sword[k] & sp_word[k])) ok = false;
+          for (int w = 0; w < KG_TWLDS; ++w) any |= mk[w] & pc.podmask[w];
+          ok = any != 0;
+        }
       }
       // ---- exact NodeClaim.Add on the survivors, in order
-      for (unsigned long long sv = __ballot(ok); sv && !placed; sv &= sv - 1) {
+      const unsigned long long sv0 = __ballot(ok);
+      KG_W(1);
+      if (WT) { wt[8] += 1; wt[9] += (unsigned long long)__popcll(sv0); }
+      for (unsigned long long sv = sv0; sv && !placed; sv &= sv - 1) {
         const uint32_t sl = (uint32_t)(__ffsll(sv) - 1);
         const unsigned long long woe = rl64(oe, sl);
         const uint32_t c = (uint32_t)woe, wnp = (uint32_t)(woe >> 32), wpos = base + sl;
@@ -331,24 +404,30 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         if (lane < Wa) bits = S.c_bits[(size_t)lane * Cmax + c];
         if (rg < NR) req = S.c_req[(size_t)rg * Cmax + c];
         if (lane < TW) cm = S.c_mask[(size_t)lane * Cmax + c];
+        int64_t phd = 0;  // lanes 0..3: the record's headroom of resources 0..3
+        if (lane < 4) phd = (int64_t)S.c_pre[(size_t)c * KG_PRE_WORDS + lane];
         const uint32_t tm_v = S.c_tmpl[c], stamp_v = S.c_stamp[c], hst_v = S.c_hstamp[c];
         const uint32_t endk = word_group_end(S, sh, nclaims, wnp, lane);  // (LDS work under the row's round trip)
         const uint32_t tm = KG_UNI(tm_v), stamp = KG_UNI(stamp_v), hst = KG_UNI(hst_v);
         const int64_t req0 = req;
         uint64_t m = cm;
         bool compat = true;
+        KG_W(2);
         const bool feasible = wave_add<false>(P, sh, pc, lane, need, tm, meta, bits, req, m, &compat);
+        KG_W(3);
+        if (WT) wt[10] += 1;
         if (!feasible) {
           if (hst != stamp) {
             // the prefilter let an infeasible claim through: recompute its headroom (its options changed since)
-            for (uint32_t r = 0; r < NR; ++r) {
+            for (uint32_t r = 0; r < NR && r < 4; ++r) {
               const int64_t mx = wave_max_over_mask(P.alloc + (size_t)KG_UNI(sh.a_res[r]) * P.T, cm, TW, lane);
               const int64_t rq = (int64_t)rl64((uint64_t)req0, 8 * r);
-              if (lane == 0) S.c_head[(size_t)r * Cmax + c] = mx - rq;
+              if (lane == 0) S.c_pre[(size_t)c * KG_PRE_WORDS + r] = (uint64_t)(mx - rq);
             }
             if (lane == 0) S.c_hstamp[c] = stamp;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           }
+          KG_W(5);
           continue;
         }
         // ---- commit: merged row back to the claim; the claim moves to the end of its pod-count group (= the front of
@@ -356,10 +435,15 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         if (lane < Ka) S.c_meta[(size_t)lane * Cmax + c] = meta;
         if (lane < Wa) S.c_bits[(size_t)lane * Cmax + c] = bits;
         if (lane < TW) S.c_mask[(size_t)lane * Cmax + c] = m;
-        if (rg < NR && (lane & 7) == 0) {
-          S.c_req[(size_t)rg * Cmax + c] = req;
-          const int64_t pq = pc.preq[rg];
-          if (pq != 0) S.c_head[(size_t)rg * Cmax + c] -= pq;
+        if (rg < NR && (lane & 7) == 0) S.c_req[(size_t)rg * Cmax + c] = req;
+        {
+          // the claim's prefilter record after this pod
+          const uint64_t sig = wave_signature(m, sgsh, lane);
+          const uint64_t zw = zslot >= 0 ? plain_set_or_all(rl32(meta, (uint32_t)zslot), rl64(bits, zoff)) : ~0ull;
+          const uint64_t cw = cslot >= 0 ? plain_set_or_all(rl32(meta, (uint32_t)cslot), rl64(bits, coff)) : ~0ull;
+          uint64_t v = (uint64_t)(phd - (lane < 4 ? pc.preq[lane < 4 ? lane : 0] : 0));
+          v = lane == 4 ? sig : (lane == 5 ? zw : (lane == 6 ? cw : (lane == 7 ? (uint64_t)tm : v)));
+          if (lane < KG_PRE_WORDS) S.c_pre[(size_t)c * KG_PRE_WORDS + lane] = v;
         }
         if (lane == 0) {
           S.c_npods[c] = wnp + 1;
@@ -379,11 +463,12 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         seq += 1;
         placed = true;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the next placement's lanes read what these lanes wrote
+        KG_W(4);
       }
     }
-    if (placed) continue;
+    if (!placed) KG_W(1);
     // ---- a new NodeClaim from each template in weight order
-    if (nclaims < (uint32_t)P.Cmax) {
+    if (!placed && nclaims < (uint32_t)P.Cmax) {
       const uint32_t c = nclaims;
       for (uint32_t t = 0; t < NP && !placed; ++t) {
         // filterByRemainingResources: types whose capacity fits what the NodePool's limits leave
@@ -420,10 +505,18 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         if (lane < Ka) S.c_meta[(size_t)lane * Cmax + c] = meta;
         if (lane < Wa) S.c_bits[(size_t)lane * Cmax + c] = bits;
         if (lane < TW) S.c_mask[(size_t)lane * Cmax + c] = m;
+        {
+          const uint64_t sig = wave_signature(m, sgsh, lane);
+          const uint64_t zw = zslot >= 0 ? plain_set_or_all(rl32(meta, (uint32_t)zslot), rl64(bits, zoff)) : ~0ull;
+          const uint64_t cw = cslot >= 0 ? plain_set_or_all(rl32(meta, (uint32_t)cslot), rl64(bits, coff)) : ~0ull;
+          const uint64_t v = lane == 4 ? sig : (lane == 5 ? zw : (lane == 6 ? cw : (uint64_t)t));
+          if (lane >= NR && lane < 4) S.c_pre[(size_t)c * KG_PRE_WORDS + lane] = 0x7FFFFFFFFFFFFFFFull;  // (no such resource: never the reason to skip)
+          if (lane >= 4 && lane < KG_PRE_WORDS) S.c_pre[(size_t)c * KG_PRE_WORDS + lane] = v;
+        }
         for (uint32_t r = 0; r < NR; ++r) {
           const int64_t mx = wave_max_over_mask(P.alloc + (size_t)KG_UNI(sh.a_res[r]) * P.T, m, TW, lane);
           const int64_t rq = (int64_t)rl64((uint64_t)req, 8 * r);
-          if (lane == 0) { S.c_req[(size_t)r * Cmax + c] = rq; S.c_head[(size_t)r * Cmax + c] = mx - rq; }
+          if (lane == 0) { S.c_req[(size_t)r * Cmax + c] = rq; if (r < 4) S.c_pre[(size_t)c * KG_PRE_WORDS + r] = (uint64_t)(mx - rq); }
           // subtractMax: the worst-case capacity of the remaining options is charged against the limits
           if (P.tmpl_has_limits[t] && P.tmpl_limit_res[(size_t)r * NP + t]) {
             const int64_t cx = wave_max_over_mask(P.cap + (size_t)KG_UNI(sh.a_res[r]) * P.T, m, TW, lane);
@@ -453,24 +546,46 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       }
     }
-    if (placed) continue;
-    // ---- Preferences.Relax + Queue.Push
-    const int32_t vnext = (int32_t)KG_UNI((uint32_t)pc.vc.v.next);
-    if (lane == 0) {
-      S.pod_kind[pod_row(S, pod)] = 0;
-      S.pod_index[pod_row(S, pod)] = -1;
-      S.pod_reason[pod_row(S, pod)] = reason ? reason : 8;
-      uint4 qn;
-      qn.x = pod;
-      if (vnext >= 0) { qn.y = (uint32_t)vnext; qn.z = 0; qn.w = 0; S.header[1] += 1; }
-      else { qn.y = variant; qn.z = epoch; qn.w = qlen + 1; }
-      ((KG_GLOBAL uint4*)S.queue)[(qhead + qlen) % QCAP] = qn;
+    KG_W(6);
+    if (!placed) {
+      // ---- Preferences.Relax + Queue.Push (the push lands behind the entries already fetched: they were only fetched
+      // when the queue held them)
+      const int32_t vnext = (int32_t)KG_UNI((uint32_t)pc.vc.v.next);
+      if (lane == 0) {
+        S.pod_kind[pod_row(S, pod)] = 0;
+        S.pod_index[pod_row(S, pod)] = -1;
+        S.pod_reason[pod_row(S, pod)] = reason ? reason : 8;
+        uint4 qn;
+        qn.x = pod;
+        if (vnext >= 0) { qn.y = (uint32_t)vnext; qn.z = 0; qn.w = 0; S.header[1] += 1; }
+        else { qn.y = variant; qn.z = epoch; qn.w = qlen + 1; }
+        ((KG_GLOBAL uint4*)S.queue)[(qhead + qlen) % QCAP] = qn;
+      }
+      qlen += 1;
+      if (vnext >= 0) epoch += 1;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_s_waitcnt(0);  // the pushed entry may be the next pop
     }
-    qlen += 1;
-    if (vnext >= 0) epoch += 1;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);  // the pushed entry may be the next pop
+    // ---- the next pod's context -> the other buffer
+    have_ctx = next_ok;
+    if (next_ok) {
+      PodCtx& nx = sh.pcb[cur ^ 1];
+      uint64_t* dst = (uint64_t*)&nx;
+      const unsigned long long nb = __ballot(n_rq != 0);
+      uint64_t w0 = iw[0];
+      if (lane < KG_MAXR) w0 = (uint64_t)n_rq;          // words 0..7: the pod's requests
+      if (lane == KG_MAXR) w0 = (uint64_t)(uint32_t)nb;  // word 8: need
+      dst[lane] = w0;
+#pragma unroll
+      for (int k = 1; k < 4; ++k) { const uint32_t i = lane + 64 * k; if (i < sizeof(PodCtx) / 8) dst[i] = iw[k]; }
+      nq_pod = n_pod; nq_variant = n_variant; nq_z = n_z; nq_w = n_w;
+    }
   }
+  if (WT && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) S.counters[64 + i] = wt[i];
+  }
+#undef KG_W
   if (lane == 0) {
     S.header[0] = nclaims;
     S.header[2] = last_c; S.header[3] = last_npods; S.header[4] = last_stamp; S.header[5] = last_new;
