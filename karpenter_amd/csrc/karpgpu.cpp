@@ -287,7 +287,7 @@ struct Compiled {
   // simulations that reschedule it): gcount index g * 64 + d, or 0x80000000 | hcount index
   std::vector<std::vector<uint32_t>> contrib;
   std::vector<uint64_t> gdom_univ;   // [G] domains registered from the NodePools / instance types alone
-  size_t o_nports, o_cports, o_cpre;
+  size_t o_nports, o_cports, o_crow = 0;  // o_crow: behind the state image (device-only, never uploaded)
   size_t o_nreq, o_creq, o_chead, o_chstamp, o_cmask, o_cbits, o_cmeta, o_cnpods, o_ctmpl, o_order, o_remaining, o_gcount, o_gdom, o_gpos, o_hcount, o_hpos, o_queue,
       o_podkind, o_excl, o_podindex, o_podreason, o_scratch, o_ordg, o_header, o_counters, o_nqueue;
   ~Compiled() {
@@ -1137,7 +1137,6 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   C.o_nreq = SA.add(nreq0);
   C.o_nports = SA.add(nports0);
   C.o_cports = SA.reserve((size_t)Cmax * 8);
-  C.o_cpre = SA.reserve(sim_mode ? 8 : (size_t)Cmax * 64);
   C.o_creq = SA.reserve((size_t)std::max(R, 1) * Cmax * 8);
   C.o_chead = SA.reserve((size_t)std::max(R, 1) * Cmax * 8);
   C.o_chstamp = SA.reserve((size_t)Cmax * 4);
@@ -1169,10 +1168,11 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   SA.bytes.resize((SA.bytes.size() + 255) & ~size_t(255), 0);
   C.state_bytes = SA.bytes.size();
   C.state_image = std::move(SA.bytes);
+  C.o_crow = C.state_bytes;
   if (sim_mode) return Cp;  // the caller lays out one slot per simulation
-  C.state_dev.bytes = C.state_bytes;
+  C.state_dev.bytes = C.state_bytes + (C.wave_ok ? (size_t)Cmax * 896 : 8);  // claim rows of the single-wave solve (KG_ROW_WORDS * 8)
   C.state_dev.ptr = hal::dmalloc(C.state_dev.bytes);
-  hal::h2d(C.state_dev.ptr, C.state_image.data(), C.state_dev.bytes);
+  hal::h2d(C.state_dev.ptr, C.state_image.data(), C.state_bytes);
   C.sim = sim_at(C, (uint8_t*)C.state_dev.ptr);
   SimState& St = C.sim;
   C.sims_dev.bytes = sizeof(SimState);
@@ -1185,7 +1185,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
 static SimState sim_at(const Compiled& C, uint8_t* base) {
   auto sptr = [&](size_t off) { return base + off; };
   SimState St{};
-  St.nports = (uint64_t*)sptr(C.o_nports); St.c_ports = (uint64_t*)sptr(C.o_cports); St.c_pre = (uint64_t*)sptr(C.o_cpre);
+  St.nports = (uint64_t*)sptr(C.o_nports); St.c_ports = (uint64_t*)sptr(C.o_cports); St.c_row = (uint64_t*)sptr(C.o_crow);
   St.nreq = (int64_t*)sptr(C.o_nreq); St.c_req = (int64_t*)sptr(C.o_creq); St.c_head = (int64_t*)sptr(C.o_chead); St.c_hstamp = (uint32_t*)sptr(C.o_chstamp); St.c_mask = (uint64_t*)sptr(C.o_cmask); St.c_bits = (uint64_t*)sptr(C.o_cbits);
   St.c_meta = (uint32_t*)sptr(C.o_cmeta); St.c_npods = (uint32_t*)sptr(C.o_cnpods); St.c_tmpl = (uint16_t*)sptr(C.o_ctmpl); St.c_stamp = (uint32_t*)sptr(C.o_order);
   St.remaining = (int64_t*)sptr(C.o_remaining); St.gcount = (int32_t*)sptr(C.o_gcount); St.gdom = (uint64_t*)sptr(C.o_gdom); St.gpos = (uint64_t*)sptr(C.o_gpos);

@@ -192,7 +192,7 @@ struct SimState {
   KG_GLOBAL int64_t* nreq;      // [R][N]
   KG_GLOBAL uint64_t* nports;   // [N] host-port ids reserved on the node (bit per entry of the solve's port vocabulary)
   KG_GLOBAL uint64_t* c_ports;  // [Cmax] ... on the NodeClaim
-  KG_GLOBAL uint64_t* c_pre;    // [Cmax][8] prefilter records of the single-wave solve (solve_wave.hpp)
+  KG_GLOBAL uint64_t* c_row;    // [Cmax][112] claim rows of the single-wave solve (solve_wave.hpp); device-only scratch behind the state image
   KG_GLOBAL int64_t* c_req;     // [R][Cmax]
   KG_GLOBAL int64_t* c_head;    // [R][Cmax] upper bound of what the claim can still take: max allocatable over its options - c_req
   KG_GLOBAL uint64_t* c_mask;   // [TW][Cmax]

@@ -193,25 +193,21 @@ __device__ __forceinline__ int64_t wave_max_over_mask(const int64_t* tab, uint64
   return wave_max_i64(mx);
 }
 
-// Prefilter record of a NodeClaim (SimState::c_pre, 64 bytes = one cache line per claim, written at every commit):
-//   [0..3] headroom of active resources 0..3 (upper bound of what the claim can still take)
-//   [4]    type signature: bit b = some remaining instance type in bucket b (types [b << sh, (b + 1) << sh))
-//   [5][6] the claim's allowed values on the zone / capacity-type keys when they are plain non-empty sets, else all ones
-//   [7]    template
-// A pod can only land on a claim whose record passes all of: headroom >= requests, signature AND the pod's signature,
-// zone / capacity-type words AND the pod's, toleration of the template -- each one a necessary condition of NodeClaim.Add.
-constexpr int KG_PRE_WORDS = 8;
-__device__ __forceinline__ uint32_t sig_shift(uint32_t TW) { uint32_t sh = 0; while ((1u << sh) < TW) ++sh; return sh; }
-// bit b of the result = mask (word w in lane w) has a type in bucket b
-__device__ __forceinline__ uint64_t wave_signature(uint64_t mask, uint32_t sh, uint32_t lane) {
-  const uint32_t per = 6 - sh;                       // buckets per 64-type word = 1 << per
-  const uint32_t wi = lane >> per;                   // word that holds bucket `lane`
-  const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)mask, (int)wi, 64), hi = (uint32_t)__shfl((int)(uint32_t)(mask >> 32), (int)wi, 64);
-  const uint64_t word = ((uint64_t)hi << 32) | lo;
-  const uint32_t width = 1u << sh;
-  const uint64_t field = (word >> ((lane & ((1u << per) - 1)) << sh)) & (width >= 64 ? ~0ull : ((1ull << width) - 1));
-  return __ballot(field != 0);
-}
+// State of a NodeClaim in the single-wave solve: ONE contiguous row per claim (SimState::c_row, 896 bytes) instead of
+// the column arrays of the workgroup kernel -- the prefilter reads its first three cache lines with consecutive 16-byte
+// loads, NodeClaim.Add reads / writes the rest with loads that are consecutive across the lanes, and the kernel keeps one
+// pointer instead of ten.  The columns the host decodes (c_mask, c_bits, c_meta, c_req, c_npods, c_tmpl, c_stamp) are
+// written from the rows once, when the Solve is over.  Words (8 bytes each):
+//   [0..3]   headroom of active resources 0..3 (upper bound of what the claim can still take)
+//   [4][5]   the claim's allowed values on the zone / capacity-type keys when they are plain non-empty sets, else all ones
+//   [6]      template | pod count << 32          [7] order stamp | stamp of the last exact headroom << 32
+//   [8..23]  option mask (zero beyond TW words)
+//   [24..31] requests per active resource        [32..47] requirement meta words (32 x 4 bytes)     [48..111] value bits
+// The prefilter part (words 0..23): a pod can only land on a claim with headroom >= requests, option mask AND the pod's
+// own type mask, zone / capacity-type words AND the pod's, a tolerated template -- each a necessary condition of
+// NodeClaim.Add.  One lane tests one claim: twelve 16-byte loads from consecutive addresses, one round trip.
+constexpr int KG_ROW_WORDS = 112, KG_ROW_MASK = 8, KG_ROW_REQ = 24, KG_ROW_META = 32, KG_ROW_BITS = 48;
+static_assert(KG_TWLDS == 16 && KG_MAXR == 8 && KG_MAXKA == 32 && KG_ROWW == 64, "row layout");
 // allowed-values word of a 1-word requirement for the record: the set itself when it is a plain non-empty set
 __device__ __forceinline__ uint64_t plain_set_or_all(uint32_t meta, uint64_t word) {
   return ((meta & (RM_PRESENT | RM_COMPL)) == RM_PRESENT && word != 0) ? word : ~0ull;
@@ -292,7 +288,6 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
   const uint32_t Ka = (uint32_t)P.Ka, Wa = (uint32_t)P.Wa, NR = (uint32_t)P.R, TW = (uint32_t)P.TW, NP = (uint32_t)P.NP;
   const size_t Cmax = (size_t)P.Cmax;
   const uint32_t rg = lane >> 3;
-  const uint32_t sgsh = sig_shift(TW);
   const int zslot = P.slot_zone >= 0 ? (int)sh.spec_slot[P.slot_zone] : -1, cslot = P.slot_ct >= 0 ? (int)sh.spec_slot[P.slot_ct] : -1;
   const uint32_t zoff = zslot >= 0 ? (uint32_t)sh.aoff[zslot] : 0, coff = cslot >= 0 ? (uint32_t)sh.aoff[cslot] : 0;
   const uint32_t QCAP = S.qcap;
@@ -349,7 +344,6 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
       const uint64_t pw = plain_set_or_all(pm, KG_UNI64(pc.vc.ebits[pb]));
       if (spec == P.slot_zone) pzone = pw; else pct = pw;
     }
-    const uint64_t psig = wave_signature(lane < TW ? pc.podmask[lane < KG_TWLDS ? lane : 0] : 0ull, sgsh, lane);
     last_c = KG_NOIDX; last_new = 0;
     uint32_t reason = 0;
     bool placed = false;
@@ -358,6 +352,9 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
     int64_t prq[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) prq[r] = pc.preq[r];
+    // what the previous placement's lanes stored is read by other lanes from here on: its stores have had the pop and
+    // the prefetch to complete in
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     // ---- in-flight NodeClaims in scan order, 64 positions per step
     for (uint32_t base = 0; base < nclaims && !placed; base += 64) {
       const uint32_t pos = base + lane;
@@ -366,28 +363,25 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
       if (pos < nclaims) {
         oe = word_get(S, sh, pos);
         const uint32_t c = (uint32_t)oe;
-        // the claim's prefilter record: one cache line, four 16-byte loads, one round trip
-        const KG_GLOBAL uint4* rec = (const KG_GLOBAL uint4*)(S.c_pre + (size_t)c * KG_PRE_WORDS);
-        const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-        const int64_t h0 = (int64_t)(((uint64_t)q0.y << 32) | q0.x), h1 = (int64_t)(((uint64_t)q0.w << 32) | q0.z);
-        const int64_t h2 = (int64_t)(((uint64_t)q1.y << 32) | q1.x), h3 = (int64_t)(((uint64_t)q1.w << 32) | q1.z);
-        const uint64_t csig = ((uint64_t)q2.y << 32) | q2.x, czone = ((uint64_t)q2.w << 32) | q2.z, cct = ((uint64_t)q3.y << 32) | q3.x;
-        const uint32_t tm = q3.z;
-        uint32_t bad = (uint32_t)(((tolw >> tm) & 1) == 0) | (uint32_t)((csig & psig) == 0) | (uint32_t)((czone & pzone) == 0) | (uint32_t)((cct & pct) == 0);
+        // the claim's prefilter record: twelve 16-byte loads from consecutive addresses, one round trip
+        const KG_GLOBAL uint4* rec = (const KG_GLOBAL uint4*)(S.c_row + (size_t)c * KG_ROW_WORDS);
+        uint4 q[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) q[k] = rec[k];
+        const int64_t h0 = (int64_t)(((uint64_t)q[0].y << 32) | q[0].x), h1 = (int64_t)(((uint64_t)q[0].w << 32) | q[0].z);
+        const int64_t h2 = (int64_t)(((uint64_t)q[1].y << 32) | q[1].x), h3 = (int64_t)(((uint64_t)q[1].w << 32) | q[1].z);
+        const uint64_t czone = ((uint64_t)q[2].y << 32) | q[2].x, cct = ((uint64_t)q[2].w << 32) | q[2].z;
+        const uint32_t tm = q[3].x;
+        uint64_t any = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          any |= ((((uint64_t)q[4 + k].y << 32) | q[4 + k].x) & pc.podmask[2 * k]) | ((((uint64_t)q[4 + k].w << 32) | q[4 + k].z) & pc.podmask[2 * k + 1]);
+        }
+        uint32_t bad = (uint32_t)(((tolw >> tm) & 1) == 0) | (uint32_t)(any == 0) | (uint32_t)((czone & pzone) == 0) | (uint32_t)((cct & pct) == 0);
         bad |= ((uint32_t)(h0 < prq[0]) & need) | ((uint32_t)(h1 < prq[1]) & (need >> 1)) | ((uint32_t)(h2 < prq[2]) & (need >> 2)) | ((uint32_t)(h3 < prq[3]) & (need >> 3));
         bad &= 1u;
         if (P.has_ports) bad |= (uint32_t)((S.c_ports[c] & hp_conf) != 0);
         ok = hcok && bad == 0;
-        if (ok) {
-          // second stage, for the few claims the record lets through: the exact option mask AND the pod's mask
-          uint64_t mk[KG_TWLDS];
-#pragma unroll
-          for (int w = 0; w < KG_TWLDS; ++w) mk[w] = S.c_mask[(size_t)((uint32_t)w < TW ? (uint32_t)w : TW - 1) * Cmax + c];
-          uint64_t any = 0;
-#pragma unroll
-          for (int w = 0; w < KG_TWLDS; ++w) any |= mk[w] & pc.podmask[w];
-          ok = any != 0;
-        }
       }
       // ---- exact NodeClaim.Add on the survivors, in order
       const unsigned long long sv0 = __ballot(ok);
@@ -400,15 +394,17 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         uint32_t meta = 0;
         uint64_t bits = 0, cm = 0;
         int64_t req = 0;
-        if (lane < Ka) meta = S.c_meta[(size_t)lane * Cmax + c];
-        if (lane < Wa) bits = S.c_bits[(size_t)lane * Cmax + c];
-        if (rg < NR) req = S.c_req[(size_t)rg * Cmax + c];
-        if (lane < TW) cm = S.c_mask[(size_t)lane * Cmax + c];
-        int64_t phd = 0;  // lanes 0..3: the record's headroom of resources 0..3
-        if (lane < 4) phd = (int64_t)S.c_pre[(size_t)c * KG_PRE_WORDS + lane];
-        const uint32_t tm_v = S.c_tmpl[c], stamp_v = S.c_stamp[c], hst_v = S.c_hstamp[c];
+        KG_GLOBAL uint64_t* row = S.c_row + (size_t)c * KG_ROW_WORDS;
+        if (lane < KG_MAXKA) meta = ((const KG_GLOBAL uint32_t*)(row + KG_ROW_META))[lane];
+        bits = row[KG_ROW_BITS + lane];
+        req = (int64_t)row[KG_ROW_REQ + rg];
+        if (lane < KG_TWLDS) cm = row[KG_ROW_MASK + lane];
+        int64_t phd = 0;  // lanes 0..3: the headroom of resources 0..3
+        if (lane < 4) phd = (int64_t)row[lane];
+        const uint64_t w6_v = row[6], w7_v = row[7];
         const uint32_t endk = word_group_end(S, sh, nclaims, wnp, lane);  // (LDS work under the row's round trip)
-        const uint32_t tm = KG_UNI(tm_v), stamp = KG_UNI(stamp_v), hst = KG_UNI(hst_v);
+        const uint64_t w6 = KG_UNI64(w6_v), w7 = KG_UNI64(w7_v);
+        const uint32_t tm = (uint32_t)w6, stamp = (uint32_t)w7, hst = (uint32_t)(w7 >> 32);
         const int64_t req0 = req;
         uint64_t m = cm;
         bool compat = true;
@@ -422,32 +418,30 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
             for (uint32_t r = 0; r < NR && r < 4; ++r) {
               const int64_t mx = wave_max_over_mask(P.alloc + (size_t)KG_UNI(sh.a_res[r]) * P.T, cm, TW, lane);
               const int64_t rq = (int64_t)rl64((uint64_t)req0, 8 * r);
-              if (lane == 0) S.c_pre[(size_t)c * KG_PRE_WORDS + r] = (uint64_t)(mx - rq);
+              if (lane == 0) row[r] = (uint64_t)(mx - rq);
             }
-            if (lane == 0) S.c_hstamp[c] = stamp;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) row[7] = (uint64_t)stamp | ((uint64_t)stamp << 32);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the next survivor's loads may read this claim's lines)
           }
           KG_W(5);
           continue;
         }
         // ---- commit: merged row back to the claim; the claim moves to the end of its pod-count group (= the front of
         // the next one)
-        if (lane < Ka) S.c_meta[(size_t)lane * Cmax + c] = meta;
-        if (lane < Wa) S.c_bits[(size_t)lane * Cmax + c] = bits;
-        if (lane < TW) S.c_mask[(size_t)lane * Cmax + c] = m;
-        if (rg < NR && (lane & 7) == 0) S.c_req[(size_t)rg * Cmax + c] = req;
+        if (lane < KG_MAXKA) ((KG_GLOBAL uint32_t*)(row + KG_ROW_META))[lane] = meta;
+        row[KG_ROW_BITS + lane] = bits;
+        if ((lane & 7) == 0) row[KG_ROW_REQ + rg] = (uint64_t)req;
+        if (lane < KG_TWLDS) row[KG_ROW_MASK + lane] = m;  // (m is zero in lanes beyond TW)
         {
-          // the claim's prefilter record after this pod
-          const uint64_t sig = wave_signature(m, sgsh, lane);
+          // the prefilter part of the row after this pod
           const uint64_t zw = zslot >= 0 ? plain_set_or_all(rl32(meta, (uint32_t)zslot), rl64(bits, zoff)) : ~0ull;
           const uint64_t cw = cslot >= 0 ? plain_set_or_all(rl32(meta, (uint32_t)cslot), rl64(bits, coff)) : ~0ull;
           uint64_t v = (uint64_t)(phd - (lane < 4 ? pc.preq[lane < 4 ? lane : 0] : 0));
-          v = lane == 4 ? sig : (lane == 5 ? zw : (lane == 6 ? cw : (lane == 7 ? (uint64_t)tm : v)));
-          if (lane < KG_PRE_WORDS) S.c_pre[(size_t)c * KG_PRE_WORDS + lane] = v;
+          const uint64_t n6 = (uint64_t)tm | ((uint64_t)(wnp + 1) << 32), n7 = (uint64_t)(seq + 1) | ((uint64_t)hst << 32);
+          v = lane == 4 ? zw : (lane == 5 ? cw : (lane == 6 ? n6 : (lane == 7 ? n7 : v)));
+          if (lane < 8) row[lane] = v;
         }
         if (lane == 0) {
-          S.c_npods[c] = wnp + 1;
-          S.c_stamp[c] = seq + 1;
           S.pod_kind[pod_row(S, pod)] = 2;
           S.pod_index[pod_row(S, pod)] = (int32_t)c;
           if (P.has_ports) S.c_ports[c] = S.c_ports[c] | pc.vc.hp_use;
@@ -462,7 +456,6 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         last_c = c; last_new = 0; last_npods = wnp; last_stamp = stamp;
         seq += 1;
         placed = true;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the next placement's lanes read what these lanes wrote
         KG_W(4);
       }
     }
@@ -502,21 +495,23 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         const bool feasible = wave_add<true>(P, sh, pc, lane, need, t, meta, bits, req, m, &compat);
         if (!feasible) { reason |= compat ? 8u : 2u; continue; }
         // ---- commit the new claim: appended to the end of the one-pod group
-        if (lane < Ka) S.c_meta[(size_t)lane * Cmax + c] = meta;
-        if (lane < Wa) S.c_bits[(size_t)lane * Cmax + c] = bits;
-        if (lane < TW) S.c_mask[(size_t)lane * Cmax + c] = m;
+        KG_GLOBAL uint64_t* row = S.c_row + (size_t)c * KG_ROW_WORDS;
+        if (lane < KG_MAXKA) ((KG_GLOBAL uint32_t*)(row + KG_ROW_META))[lane] = meta;
+        row[KG_ROW_BITS + lane] = bits;
+        if ((lane & 7) == 0) row[KG_ROW_REQ + rg] = (uint64_t)req;
+        if (lane < KG_TWLDS) row[KG_ROW_MASK + lane] = m;
         {
-          const uint64_t sig = wave_signature(m, sgsh, lane);
           const uint64_t zw = zslot >= 0 ? plain_set_or_all(rl32(meta, (uint32_t)zslot), rl64(bits, zoff)) : ~0ull;
           const uint64_t cw = cslot >= 0 ? plain_set_or_all(rl32(meta, (uint32_t)cslot), rl64(bits, coff)) : ~0ull;
-          const uint64_t v = lane == 4 ? sig : (lane == 5 ? zw : (lane == 6 ? cw : (uint64_t)t));
-          if (lane >= NR && lane < 4) S.c_pre[(size_t)c * KG_PRE_WORDS + lane] = 0x7FFFFFFFFFFFFFFFull;  // (no such resource: never the reason to skip)
-          if (lane >= 4 && lane < KG_PRE_WORDS) S.c_pre[(size_t)c * KG_PRE_WORDS + lane] = v;
+          const uint64_t n6 = (uint64_t)t | (1ull << 32), n7 = (uint64_t)(seq + 1) | ((uint64_t)(seq + 1) << 32);
+          const uint64_t v = lane == 4 ? zw : (lane == 5 ? cw : (lane == 6 ? n6 : n7));
+          if (lane >= NR && lane < 4) row[lane] = 0x7FFFFFFFFFFFFFFFull;  // (no such resource: never the reason to skip)
+          if (lane >= 4 && lane < 8) row[lane] = v;
         }
         for (uint32_t r = 0; r < NR; ++r) {
           const int64_t mx = wave_max_over_mask(P.alloc + (size_t)KG_UNI(sh.a_res[r]) * P.T, m, TW, lane);
           const int64_t rq = (int64_t)rl64((uint64_t)req, 8 * r);
-          if (lane == 0) { S.c_req[(size_t)r * Cmax + c] = rq; if (r < 4) S.c_pre[(size_t)c * KG_PRE_WORDS + r] = (uint64_t)(mx - rq); }
+          if (lane == 0 && r < 4) row[r] = (uint64_t)(mx - rq);
           // subtractMax: the worst-case capacity of the remaining options is charged against the limits
           if (P.tmpl_has_limits[t] && P.tmpl_limit_res[(size_t)r * NP + t]) {
             const int64_t cx = wave_max_over_mask(P.cap + (size_t)KG_UNI(sh.a_res[r]) * P.T, m, TW, lane);
@@ -524,7 +519,6 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
           }
         }
         if (lane == 0) {
-          S.c_npods[c] = 1; S.c_tmpl[c] = (uint16_t)t; S.c_hstamp[c] = seq + 1; S.c_stamp[c] = seq + 1;
           S.pod_kind[pod_row(S, pod)] = 2;
           S.pod_index[pod_row(S, pod)] = (int32_t)c;
           if (P.has_ports) S.c_ports[c] = pc.vc.hp_use;
@@ -543,7 +537,6 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         last_c = c; last_new = 1;
         nclaims += 1; seq += 1;
         placed = true;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       }
     }
     KG_W(6);
@@ -579,6 +572,19 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
 #pragma unroll
       for (int k = 1; k < 4; ++k) { const uint32_t i = lane + 64 * k; if (i < sizeof(PodCtx) / 8) dst[i] = iw[k]; }
       nq_pod = n_pod; nq_variant = n_variant; nq_z = n_z; nq_w = n_w;
+    }
+  }
+  // ---- the columns the host decodes, from the rows
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  for (uint32_t c = 0; c < nclaims; ++c) {
+    const KG_GLOBAL uint64_t* row = S.c_row + (size_t)c * KG_ROW_WORDS;
+    if (lane < Ka) S.c_meta[(size_t)lane * Cmax + c] = ((const KG_GLOBAL uint32_t*)(row + KG_ROW_META))[lane];
+    if (lane < Wa) S.c_bits[(size_t)lane * Cmax + c] = row[KG_ROW_BITS + lane];
+    if (lane < NR) S.c_req[(size_t)lane * Cmax + c] = (int64_t)row[KG_ROW_REQ + lane];
+    if (lane < TW) S.c_mask[(size_t)lane * Cmax + c] = row[KG_ROW_MASK + lane];
+    if (lane == 0) {
+      const uint64_t w6 = row[6], w7 = row[7];
+      S.c_tmpl[c] = (uint16_t)(uint32_t)w6; S.c_npods[c] = (uint32_t)(w6 >> 32); S.c_stamp[c] = (uint32_t)w7;
     }
   }
   if (WT && lane == 0) {
