@@ -46,12 +46,12 @@ __global__ void __launch_bounds__(256) k_pod_ctx(DevProblem P, PrepassTables X) 
 }
 
 // k_solve: one workgroup = one Scheduler.Solve (persistent over the whole pod queue)
-template <int NT>
+template <int NT, bool DBG>
 __global__ void __launch_bounds__(NT) k_solve(DevProblem Pin, const SimState* sims, const uint32_t* nqueue) {
   __shared__ Shared sh;
   const DevProblem& P = Pin;
   const SimState S = sims[blockIdx.x];
-  if (P.stats & 2) {
+  if (DBG && (P.stats & 2)) {
     // micro-probes (debug timers only): cost of a bare barrier, of a dependent global load chain, of a flat LDS access
     __shared__ uint32_t probe[64];
     unsigned long long t0 = wall_clock64();
@@ -111,8 +111,8 @@ __global__ void __launch_bounds__(NT) k_solve(DevProblem Pin, const SimState* si
     __syncthreads();
   }
   const unsigned long long c0 = clock64(), w0 = wall_clock64();
-  solve_block<NT>(P, S, sh, nqueue[blockIdx.x]);
-  if ((P.stats & 2) && threadIdx.x == 0) { S.counters[24] = clock64() - c0; S.counters[25] = wall_clock64() - w0; }
+  solve_block<NT, DBG>(P, S, sh, nqueue[blockIdx.x]);
+  if (DBG && (P.stats & 2) && threadIdx.x == 0) { S.counters[24] = clock64() - c0; S.counters[25] = wall_clock64() - w0; }
 }
 
 // k_simulate: the same solve loop, one workgroup per consolidation simulation (a kernel of its own so that profiles keep
@@ -122,15 +122,16 @@ __global__ void __launch_bounds__(NT) k_simulate(DevProblem Pin, const SimState*
   __shared__ Shared sh;
   const DevProblem& P = Pin;
   const SimState S = sims[blockIdx.x];
-  solve_block<NT>(P, S, sh, nqueue[blockIdx.x]);
+  solve_block<NT, false>(P, S, sh, nqueue[blockIdx.x]);
 }
 
 // k_solve_wave: one WAVE = one Scheduler.Solve (solve_wave.hpp: batches without topology groups / existing nodes / minValues)
+template <bool DBG>
 __global__ void __launch_bounds__(64) k_solve_wave(DevProblem Pin, const SimState* sims, const uint32_t* nqueue) {
   __shared__ Shared sh;
   const DevProblem& P = Pin;
   const SimState S = sims[blockIdx.x];
-  solve_wave(P, S, sh, nqueue[blockIdx.x]);
+  solve_wave<DBG>(P, S, sh, nqueue[blockIdx.x]);
 }
 
 // k_sim_init: one workgroup per simulation copies the pristine state image into its slot and applies the patches
@@ -206,15 +207,17 @@ void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const ui
     *ms = t.stop();
     return;
   }
-  if (block >= 1024) hipLaunchKernelGGL((k_solve<1024>), dim3(nsims), dim3(1024), 0, 0, P, sims, nqueue);
-  else if (block >= 512) hipLaunchKernelGGL((k_solve<512>), dim3(nsims), dim3(512), 0, 0, P, sims, nqueue);
-  else hipLaunchKernelGGL((k_solve<256>), dim3(nsims), dim3(256), 0, 0, P, sims, nqueue);
+  if (P.stats & (2 | 8)) hipLaunchKernelGGL((k_solve<256, true>), dim3(nsims), dim3(256), 0, 0, P, sims, nqueue);  // debug timers: 256 threads only
+  else if (block >= 1024) hipLaunchKernelGGL((k_solve<1024, false>), dim3(nsims), dim3(1024), 0, 0, P, sims, nqueue);
+  else if (block >= 512) hipLaunchKernelGGL((k_solve<512, false>), dim3(nsims), dim3(512), 0, 0, P, sims, nqueue);
+  else hipLaunchKernelGGL((k_solve<256, false>), dim3(nsims), dim3(256), 0, 0, P, sims, nqueue);
   ck(hipGetLastError(), "solve launch");
   *ms = t.stop();
 }
 void launch_solve_wave(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, float* ms) {
   Timer t;
-  hipLaunchKernelGGL(k_solve_wave, dim3(nsims), dim3(64), 0, 0, P, sims, nqueue);
+  if (P.stats & 8) hipLaunchKernelGGL((k_solve_wave<true>), dim3(nsims), dim3(64), 0, 0, P, sims, nqueue);
+  else hipLaunchKernelGGL((k_solve_wave<false>), dim3(nsims), dim3(64), 0, 0, P, sims, nqueue);
   ck(hipGetLastError(), "solve (wave) launch");
   *ms = t.stop();
 }

@@ -36,9 +36,9 @@ void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const ui
   for (int i = 0; i < nsims; ++i) {
     static Shared sh;
     std::memset(&sh, 0, sizeof sh);
-    if (block >= 1024) solve_block<1024>(P, sims[i], sh, nqueue[i]);
-    else if (block >= 512) solve_block<512>(P, sims[i], sh, nqueue[i]);
-    else solve_block<256>(P, sims[i], sh, nqueue[i]);
+    if (block >= 1024) solve_block<1024, false>(P, sims[i], sh, nqueue[i]);
+    else if (block >= 512) solve_block<512, false>(P, sims[i], sh, nqueue[i]);
+    else solve_block<256, false>(P, sims[i], sh, nqueue[i]);
   }
   *ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }

@@ -1161,17 +1161,18 @@ KG_HD void stage_tables(const DevProblem& P, Shared& sh) {
 // a barrier AND is at least one barrier after the last uniform read of it -- otherwise a fast wave overwrites it while
 // a slow wave has not branched yet, and the waves' barrier counts diverge.  Words written once per pass alternate
 // between two slots for that reason (feas, mvf, fresh_lim).
-template <int NT>
+// DBG: with the phase timers and the per-wave cycle accounting (debug builds of the kernel only: their counters cost registers)
+template <int NT, bool DBG>
 KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint32_t n_queue) {
   const bool STATS = (P.stats & 1) != 0;
-  const bool TIMERS = (P.stats & 2) != 0;  // per-phase wall-clock ticks (100 MHz) of thread 0 into counters[8..]
+  const bool TIMERS = DBG && (P.stats & 2) != 0;  // per-phase wall-clock ticks (100 MHz) of thread 0 into counters[8..]
   unsigned long long t_mark = 0;
 #define KG_T(i) do { if (TIMERS) { KG_FOR_THREADS(tid, NT) { if (tid == 0) { const unsigned long long n_ = now_ticks(); if (t_mark) S.counters[8 + (i)] += n_ - t_mark; t_mark = n_; } } } } while (0)
   // (inside a phase body: thread 0's own progress, counters[32 + k])
 #define KG_ST(k) do { if (TIMERS && tid == 0) { const unsigned long long n_ = now_ticks(); if (t_mark) S.counters[32 + (k)] += n_ - t_mark; t_mark = n_; } } while (0)
   // per-wave cycle accounting (stats & 8): work / barrier wait of every phase kind, kept in registers, written at the end
 #if KG_DEVICE_ONLY
-  const bool WT = (P.stats & 8) != 0;
+  const bool WT = DBG && (P.stats & 8) != 0;
   unsigned long long wt_last = 0, wt[32];
 #pragma unroll
   for (int i = 0; i < 32; ++i) wt[i] = 0;

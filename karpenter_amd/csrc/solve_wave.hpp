@@ -276,10 +276,12 @@ __device__ __forceinline__ void ctx_fetch_image(const DevProblem& P, PodCtx& nx,
 
 // The whole Solve.  Preconditions (checked by the host before it picks this kernel): no topology groups, no existing
 // nodes, no minValues, TW <= KG_TWLDS, every table stages into LDS, visit counters off.
+// DBG: with the per-section cycle accounting (its counters would otherwise cost the production kernel two dozen scalar registers)
+template <bool DBG>
 __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& S, Shared& sh, uint32_t n_queue) {
   const uint32_t lane = threadIdx.x & 63;
   // cycle accounting per section of a placement (stats & 8; debug): registers, written once at the end
-  const bool WT = (P.stats & 8) != 0;
+  constexpr bool WT = DBG;
   unsigned long long wt_last = 0, wt[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) wt[i] = 0;
