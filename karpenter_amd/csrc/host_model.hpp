@@ -176,6 +176,15 @@ struct Arena {
     bytes.resize(off + std::max<size_t>(nbytes, 8), 0);
     return off;
   }
+  // Space behind the host image that only the device touches (kernel outputs, per-claim state): it costs no host memory,
+  // no zero fill and no upload.  Every add() / reserve() must come before the first reserve_tail().
+  size_t tail_end = 0;
+  size_t reserve_tail(size_t nbytes) {
+    size_t off = (std::max(bytes.size(), tail_end) + 255) & ~size_t(255);
+    tail_end = off + std::max<size_t>(nbytes, 8);
+    return off;
+  }
+  size_t total() const { return (std::max(bytes.size(), tail_end) + 255) & ~size_t(255); }
 };
 
 // ---------------------------------------------------------------- catalog (host view + device tables)

@@ -279,7 +279,7 @@ struct Compiled {
   DeviceBuffer prob_dev, state_dev, sims_dev;
   SimState sim{};  // device pointers
   std::vector<uint8_t> state_image;
-  size_t state_bytes = 0;
+  size_t state_bytes = 0, state_init_bytes = 0;  // whole state slot / its initialised prefix (the only part uploaded for a Solve)
   uint32_t qcap = 0;
   bool wave_ok = false;  // the single-wave solve applies (no topology groups, no existing nodes, no minValues, tables fit LDS)
   std::vector<uint32_t> queue_order, pod_variant0;  // pods in Queue order; initial variant of every pod
@@ -355,7 +355,21 @@ struct SolveInputs {
 };
 
 // Builds every device table for one Solve over `in.pending`.
+// KG_HOST_PROF=1: wall time of every section of compile_problem to stderr (host-side tuning aid)
+struct HostProf {
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  const char* name = "start";
+  bool on = getenv("KG_HOST_PROF") != nullptr;
+  void mark(const char* next) {
+    if (!on) return;
+    auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[kg host] %-42s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n; name = next;
+  }
+};
+#define KG_PROF(x) prof_.mark(x)
 static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool stats) {
+  HostProf prof_;
   kg_ctx* ctx = in.ctx;
   Vocab& V = ctx->V;
   auto Cp = std::make_unique<Compiled>();
@@ -365,6 +379,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   const kg_nodepools_desc* nps = in.nps;
   const kg_pools& npp = nps->pools;
 
+  KG_PROF("templates (NodePools ordered by weight d");
   // ---- templates (NodePools ordered by weight desc, stable)
   std::set<uint32_t> well_known;
   for (uint32_t v : kgdesc::values(npp, nps->well_known_labels)) well_known.insert(V.key(kgdesc::str(npp.strings, v)));
@@ -397,6 +412,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   if (NP == 0 || NP > 64) throw Unsupported("need 1..64 nodepools");
   C.NP = NP;
 
+  KG_PROF("relax chains per pod class");
   // ---- relax chains per pod class
   const ParsedPods& PP = *in.pending;
   const size_t NC = PP.classes.size();
@@ -411,6 +427,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     }
   }
 
+  KG_PROF("topology groups (all created at NewTopol");
   // ---- topology groups (all created at NewTopology from the unrelaxed specs)
   std::vector<HGroup> groups;
   Interner ginterner, iinterner;
@@ -508,6 +525,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   if (G > 65535) throw Unsupported("too many topology groups");
   C.G = G;
 
+  KG_PROF("requirement sets of every variant, templ");
   // ---- requirement sets of every variant, template and node filter
   std::vector<HReqs>& reqsets = C.reqsets;
   std::unordered_map<std::string, uint32_t> rsmap;
@@ -562,6 +580,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   if (tolsets.size() > 4096) throw Unsupported("too many toleration sets");
   const int TS = (int)std::max<size_t>(tolsets.size(), 1);
 
+  KG_PROF("active keys: every key of a requirement ");
   // ---- active keys: every key of a requirement set (except hostname) + non-hostname topology keys
   std::vector<uint8_t> is_active(V.keys.size(), 0), is_topo(V.keys.size(), 0);
   for (auto& r : reqsets) for (auto& q : r.rs) if (q.key != ctx->kHostname) is_active[q.key] = 1;
@@ -599,6 +618,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   const int nspec = (int)C.spec_slot.size();
   auto spec_of_key = [&](uint32_t key) { int a = find_slot(C, key); return a < 0 ? -1 : (int)C.slot2spec[a]; };
 
+  KG_PROF("bounds tables");
   // ---- bounds tables
   std::vector<std::vector<int64_t>> gts(Ka), lts(Ka);
   for (auto& r : reqsets)
@@ -635,11 +655,13 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   auto gt_idx = [&](int a, int64_t x) { return (uint32_t)(std::lower_bound(gts[a].begin(), gts[a].end(), x) - gts[a].begin()) + 1; };
   auto lt_idx = [&](int a, int64_t x) { return (uint32_t)(std::lower_bound(lts[a].begin(), lts[a].end(), x) - lts[a].begin()) + 1; };
 
+  KG_PROF("requirement-set rows");
   // ---- requirement-set rows
   std::vector<uint32_t> rs_off(S + 1, 0), e_meta, e_bits, rs_host_meta(std::max(S, 1), 0), rs_host_off(S + 1, 0), rs_host_nodes;
   std::vector<uint8_t> e_slot;
   std::vector<uint64_t> rs_bits;
   std::vector<uint8_t> rs_host_claim_ok(std::max(S, 1), 1);
+  KG_PROF("existing nodes (needed for hostname list");
   // ---- existing nodes (needed for hostname lists): scan order
   std::vector<const CNode*> nodes;
   if (cl) {
@@ -680,6 +702,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   rs_host_off[S] = (uint32_t)rs_host_nodes.size();
   const uint32_t E = (uint32_t)e_slot.size();
 
+  KG_PROF("resources and catalog tables");
   // ---- resources and catalog tables
   // intern every resource name first, then make sure the catalog tables cover them
   // active resources: requested by a pending pod, part of a template's daemon overhead, or named by a limit.
@@ -704,6 +727,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   const int T = (int)CT.T, TW = (int)CT.TW;
   C.T = T; C.TW = TW;
 
+  KG_PROF("lists, variants");
   // ---- lists, variants
   std::vector<ListEntry> lists;
   std::vector<Variant> variants;
@@ -762,6 +786,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     class_variant0[ci] = (uint32_t)next;
   }
 
+  KG_PROF("pods");
   // ---- pods
   const int P = (int)PP.pods.size();
   C.P = P;
@@ -785,6 +810,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     });
   }
 
+  KG_PROF("templates -> device rows");
   // ---- templates -> device rows
   std::vector<int64_t> tmpl_req((size_t)std::max(R, 1) * NP, 0), tmpl_limits0((size_t)std::max(R, 1) * NP, std::numeric_limits<int64_t>::max());
   std::vector<uint8_t> tmpl_has_limits(NP, 0), tmpl_limit_res((size_t)std::max(R, 1) * NP, 0);
@@ -819,6 +845,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     }
   }
 
+  KG_PROF("nodes -> device rows");
   // ---- nodes -> device rows
   std::vector<int64_t> navail((size_t)std::max(R, 1) * std::max(N, 1), 0), nreq0(navail.size(), 0);
   std::vector<uint16_t> nval((size_t)std::max(Ka, 1) * std::max(N, 1), 0xFFFF), ndom((size_t)std::max(nspec, 1) * std::max(N, 1), 0xFFFF);
@@ -862,6 +889,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     }
   }
 
+  KG_PROF("topology: domain universe, initial count");
   // ---- topology: domain universe, initial counts
   std::vector<Group> dgroups(std::max(G, 1));
   std::vector<uint64_t> gdom0(std::max(G, 1), 0), gpos0(std::max(G, 1), 0);
@@ -978,6 +1006,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     for (size_t i = 0; i < idx.size() && idx[i] < 64; ++i) vrank[sp * 64 + idx[i]] = (uint16_t)i;
   }
 
+  KG_PROF("host ports (scheduling.HostPortUsage): t");
   // ---- host ports (scheduling.HostPortUsage): the distinct (ip, port, protocol) entries of this solve's pods form a
   // vocabulary of <= 64 ids; a node / NodeClaim holds the ids reserved on it in one word, a pod class the ids it reserves
   // and the ids that conflict with one of them (same port and protocol, equal ips or either one 0.0.0.0)
@@ -1010,6 +1039,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     }
   }
 
+  KG_PROF("one precompiled record per pod variant (");
   // ---- one precompiled record per pod variant (what NodeClaim.Add / ExistingNode.Add need of the pod)
   const int NV = (int)variants.size();
   std::vector<VariantCtx> vctx(std::max(NV, 1));
@@ -1050,6 +1080,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     }
   }
 
+  KG_PROF("per-slot catalog views");
   // ---- per-slot catalog views
   std::vector<uint64_t> kU((size_t)std::max(Ka, 1) * TW, 0), kN((size_t)std::max(Ka, 1) * TW, 0);
   std::vector<uint32_t> ktwv_off(std::max(Ka, 1), 0);
@@ -1060,21 +1091,27 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     if (CT.key_row_off[k] != UINT32_MAX) { ktwv_off[a] = CT.key_row_off[k]; ktwv_n[a] = (uint16_t)CT.key_nvals[k]; }
   }
 
+  KG_PROF("pack the problem image");
   // ---- pack the problem image
   Arena A;
   const size_t o_aoff = A.add(C.aoff), o_aw = A.add(C.aw), o_s2s = A.add(C.slot2spec), o_ss = A.add(C.spec_slot), o_kU = A.add(kU), o_kN = A.add(kN),
                o_ktoff = A.add(ktwv_off), o_ktn = A.add(ktwv_n), o_vrank = A.add(vrank), o_bnd = A.add(bnd_off), o_gtval = A.add(gtval),
                o_ltval = A.add(ltval), o_gtmask = A.add(gtmask), o_ltmask = A.add(ltmask), o_bmo = A.add(bndmask_off), o_rsoff = A.add(rs_off),
                o_eslot = A.add(e_slot), o_emeta = A.add(e_meta), o_ebits = A.add(e_bits), o_rsbits = A.add(rs_bits),
-               o_amask = A.reserve((size_t)std::max(E, 1u) * TW * 8), o_vctx = A.add(vctx), o_podmask = A.reserve((size_t)std::max(NV, 1) * TW * 8), o_pctx = A.reserve(sim_mode ? 8 : (size_t)std::max(NV, 1) * sizeof(PodCtx)), o_atab = A.reserve(5 * KG_MAXR * 4), o_pv0 = A.add(pod_variant0), o_preq = A.add(preq),
+               o_vctx = A.add(vctx), o_pv0 = A.add(pod_variant0), o_preq = A.add(preq),
                o_queue0 = A.add(queue0), o_lists = A.add(lists), o_tmplrs = A.add(tmpl_rs), o_tmplreq = A.add(tmpl_req),
                o_thl = A.add(tmpl_has_limits), o_tl0 = A.add(tmpl_limits0), o_tlr = A.add(tmpl_limit_res), o_toltmpl = A.add(tol_tmpl),
                o_minvoff = A.add(tmpl_minv_off), o_minvslot = A.add(minv_slot), o_minvmin = A.add(minv_min), o_navail = A.add(navail),
-               o_nlab = A.reserve((size_t)std::max(S, 1) * NW * 8), o_ntol = A.add(ntol), o_ndom = A.add(ndom), o_groups = A.add(dgroups),
+               o_ntol = A.add(ntol), o_ndom = A.add(ndom), o_groups = A.add(dgroups),
                o_filters = A.add(filters), o_nval = A.add(nval), o_rhm = A.add(rs_host_meta), o_rho = A.add(rs_host_off), o_rhn = A.add(rs_host_nodes);
-  C.prob_dev.bytes = A.bytes.size();
+  // kernel outputs (and the small table uploaded below) live behind the host image: never materialised on the host
+  const size_t o_amask = A.reserve_tail((size_t)std::max(E, 1u) * TW * 8), o_podmask = A.reserve_tail((size_t)std::max(NV, 1) * TW * 8),
+               o_pctx = A.reserve_tail(sim_mode ? 8 : (size_t)std::max(NV, 1) * sizeof(PodCtx)), o_atab = A.reserve_tail(5 * KG_MAXR * 4),
+               o_nlab = A.reserve_tail((size_t)std::max(S, 1) * NW * 8);
+  C.prob_dev.bytes = A.total();
   C.prob_dev.ptr = hal::dmalloc(C.prob_dev.bytes);
-  hal::h2d(C.prob_dev.ptr, A.bytes.data(), C.prob_dev.bytes);
+  hal::h2d(C.prob_dev.ptr, A.bytes.data(), A.bytes.size());
+  hal::dzero((uint8_t*)C.prob_dev.ptr + A.bytes.size(), C.prob_dev.bytes - A.bytes.size());
   auto dptr = [&](size_t off) { return (uint8_t*)C.prob_dev.ptr + off; };
   auto cptr = [&](size_t off) { return (uint8_t*)CT.dev.ptr + off; };
   DevProblem& D = C.dp;
@@ -1129,23 +1166,15 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   X.E = E; X.nval = (const uint16_t*)dptr(o_nval); X.rs_host_meta = (const uint32_t*)dptr(o_rhm); X.rs_host_off = (const uint32_t*)dptr(o_rho);
   X.rs_host_nodes = (const uint32_t*)dptr(o_rhn); X.e_amask_out = (uint64_t*)dptr(o_amask); X.nlab_out = (uint64_t*)dptr(o_nlab); X.podmask_out = (uint64_t*)dptr(o_podmask); X.pctx_out = sim_mode ? nullptr : (PodCtx*)dptr(o_pctx);
 
+  KG_PROF("simulation state image");
   // ---- simulation state image
   Arena SA;
   std::vector<int64_t> remaining0(tmpl_limits0);
   std::vector<uint32_t> header(16, 0), nqueue{(uint32_t)P};
   std::vector<uint64_t> counters(64 + 16 * 32, 0);  // [64..): per-wave cycle accounting (16 waves x 16 slots)
+  // initialised state first (it is what gets uploaded), per-claim / per-pod arrays behind it (zeroed on the device)
   C.o_nreq = SA.add(nreq0);
   C.o_nports = SA.add(nports0);
-  C.o_cports = SA.reserve((size_t)Cmax * 8);
-  C.o_creq = SA.reserve((size_t)std::max(R, 1) * Cmax * 8);
-  C.o_chead = SA.reserve((size_t)std::max(R, 1) * Cmax * 8);
-  C.o_chstamp = SA.reserve((size_t)Cmax * 4);
-  C.o_cmask = SA.reserve((size_t)TW * Cmax * 8);
-  C.o_cbits = SA.reserve((size_t)C.Wa * Cmax * 8);
-  C.o_cmeta = SA.reserve((size_t)std::max(Ka, 1) * Cmax * 4);
-  C.o_cnpods = SA.reserve((size_t)Cmax * 4);
-  C.o_ctmpl = SA.reserve((size_t)Cmax * 2);
-  C.o_order = SA.reserve((size_t)Cmax * 4);
   C.o_remaining = SA.add(remaining0);
   C.o_gcount = SA.add(gcount0); C.o_gdom = SA.add(gdom0); C.o_gpos = SA.add(gpos0); C.o_hcount = SA.add(hcount0); C.o_hpos = SA.add(hpos0);
   // Queue ring entries {pod, variant, lastLen epoch, lastLen value}
@@ -1156,28 +1185,42 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   C.queue_order = queue0;
   C.pod_variant0 = pod_variant0;
   C.o_queue = SA.add(queue);
-  C.o_podkind = SA.reserve((size_t)PR);
-  C.o_podindex = SA.reserve((size_t)PR * 4);
-  C.o_podreason = SA.reserve((size_t)PR * 4);
-  C.o_excl = SA.reserve((size_t)NW * 8);
-  C.o_scratch = SA.reserve((size_t)(TW + 1) * Cmax * 8);
-  C.o_ordg = SA.reserve((size_t)2 * Cmax * 8);
   C.o_header = SA.add(header);
   C.o_counters = SA.add(counters);
   C.o_nqueue = SA.add(nqueue);
-  SA.bytes.resize((SA.bytes.size() + 255) & ~size_t(255), 0);
-  C.state_bytes = SA.bytes.size();
+  C.state_init_bytes = (SA.bytes.size() + 255) & ~size_t(255);
+  C.o_cports = SA.reserve_tail((size_t)Cmax * 8);
+  C.o_creq = SA.reserve_tail((size_t)std::max(R, 1) * Cmax * 8);
+  C.o_chead = SA.reserve_tail((size_t)std::max(R, 1) * Cmax * 8);
+  C.o_chstamp = SA.reserve_tail((size_t)Cmax * 4);
+  C.o_cmask = SA.reserve_tail((size_t)TW * Cmax * 8);
+  C.o_cbits = SA.reserve_tail((size_t)C.Wa * Cmax * 8);
+  C.o_cmeta = SA.reserve_tail((size_t)std::max(Ka, 1) * Cmax * 4);
+  C.o_cnpods = SA.reserve_tail((size_t)Cmax * 4);
+  C.o_ctmpl = SA.reserve_tail((size_t)Cmax * 2);
+  C.o_order = SA.reserve_tail((size_t)Cmax * 4);
+  C.o_podkind = SA.reserve_tail((size_t)PR);
+  C.o_podindex = SA.reserve_tail((size_t)PR * 4);
+  C.o_podreason = SA.reserve_tail((size_t)PR * 4);
+  C.o_excl = SA.reserve_tail((size_t)NW * 8);
+  C.o_scratch = SA.reserve_tail((size_t)(TW + 1) * Cmax * 8);
+  C.o_ordg = SA.reserve_tail((size_t)2 * Cmax * 8);
+  C.state_bytes = SA.total();
+  if (sim_mode) SA.bytes.resize(C.state_bytes, 0);  // (the batches copy the whole pristine image into every simulation's slot)
+  else SA.bytes.resize(C.state_init_bytes, 0);
   C.state_image = std::move(SA.bytes);
   C.o_crow = C.state_bytes;
   if (sim_mode) return Cp;  // the caller lays out one slot per simulation
   C.state_dev.bytes = C.state_bytes + (C.wave_ok ? (size_t)Cmax * 896 : 8);  // claim rows of the single-wave solve (KG_ROW_WORDS * 8)
   C.state_dev.ptr = hal::dmalloc(C.state_dev.bytes);
-  hal::h2d(C.state_dev.ptr, C.state_image.data(), C.state_bytes);
+  hal::h2d(C.state_dev.ptr, C.state_image.data(), C.state_init_bytes);
+  hal::dzero((uint8_t*)C.state_dev.ptr + C.state_init_bytes, C.state_bytes - C.state_init_bytes);
   C.sim = sim_at(C, (uint8_t*)C.state_dev.ptr);
   SimState& St = C.sim;
   C.sims_dev.bytes = sizeof(SimState);
   C.sims_dev.ptr = hal::dmalloc(sizeof(SimState));
   hal::h2d(C.sims_dev.ptr, &St, sizeof(SimState));
+  KG_PROF("end");
   return Cp;
 }
 

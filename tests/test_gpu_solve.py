@@ -116,6 +116,15 @@ def test_catalog_update_offerings_in_place(L):
     check_updates(L)
 
 
+@pytest.fixture()
+def LW():
+    """A fresh context per test: the single-wave kernel applies while the context's vocabulary of 1-word keys (zones ...) is
+    small enough to stage in LDS, and a context shared with other tests accumulates every zone name they used."""
+    l = lib.Library()
+    yield l
+    l.close()
+
+
 def _check_wave(L, prob, expect_wave=True):
     """Visit counters off = the production setting; batches without topology groups / existing nodes / minValues are
     served by the single-wave kernel (k_solve_wave), everything else by the workgroup kernel: same results either way."""
@@ -133,32 +142,32 @@ def _check_wave(L, prob, expect_wave=True):
     return ro, rg
 
 
-def test_wave_kernel_c1_c2(L):
+def test_wave_kernel_c1_c2(LW):
     zones, types = catalog776()
-    _check_wave(L, Problem(types, wl.homogeneous_pods(1000), [wl.default_nodepool(capacity_types=("on-demand",))]))
+    _check_wave(LW, Problem(types, wl.homogeneous_pods(1000), [wl.default_nodepool(capacity_types=("on-demand",))]))
     fams = families(types)
     for n, seed in ((1, 1), (2, 1), (7, 2), (55, 2), (300, 1), (2000, 42)):
-        _check_wave(L, Problem(types, wl.mixed_pods(n, seed, zones, fams), [wl.default_nodepool()]))
+        _check_wave(LW, Problem(types, wl.mixed_pods(n, seed, zones, fams), [wl.default_nodepool()]))
 
 
-def test_wave_kernel_c2_full(L):
+def test_wave_kernel_c2_full(LW):
     zones, types = catalog776()
-    ro, rg = _check_wave(L, Problem(types, wl.mixed_pods(10000, 42, zones, families(types)), [wl.default_nodepool()]))
+    ro, rg = _check_wave(LW, Problem(types, wl.mixed_pods(10000, 42, zones, families(types)), [wl.default_nodepool()]))
     print("C2 full, single-wave kernel: device %.2f ms" % rg.res.device_ms)
 
 
-def test_wave_kernel_weighted_nodepools_with_limits(L):
+def test_wave_kernel_weighted_nodepools_with_limits(LW):
     """Fresh NodeClaims from four weighted NodePools, two of them with cpu limits that run out (subtractMax), 6 zones."""
     z6, t6 = catalog776(6)
     from tests.helpers import c5_nodepools
-    _check_wave(L, Problem(t6, wl.mixed_pods(6000, 99, z6, families(t6)), c5_nodepools()))
+    _check_wave(LW, Problem(t6, wl.mixed_pods(6000, 99, z6, families(t6)), c5_nodepools()))
 
 
-def test_wave_kernel_host_ports(L):
-    _check_wave(L, scenario("host_ports"))
+def test_wave_kernel_host_ports(LW):
+    _check_wave(LW, scenario("host_ports"))
 
 
-def test_wave_kernel_unschedulable_and_relaxation(L):
+def test_wave_kernel_unschedulable_and_relaxation(LW):
     """Pods nothing can hold (relax / re-push / lastLen stop), preferred terms that relax away, a tainted NodePool."""
     zones, types = catalog776()
     pods = wl.mixed_pods(400, 31, zones, families(types))
@@ -169,15 +178,15 @@ def test_wave_kernel_unschedulable_and_relaxation(L):
             p["preferred_terms"] = [(10, [("karpenter.k8s.aws/instance-family", "In", ["nosuchfamily"])]), (5, [(wl.L_ARCH, "In", ["arm64"])])]
     tainted = wl.default_nodepool("tainted", weight=10)
     tainted["taints"] = [("dedicated", "x", "NoSchedule")]
-    _check_wave(L, Problem(types, pods, [tainted, wl.default_nodepool()]))
+    _check_wave(LW, Problem(types, pods, [tainted, wl.default_nodepool()]))
 
 
-def test_wave_kernel_scan_order_beyond_lds(L):
+def test_wave_kernel_scan_order_beyond_lds(LW):
     """> 4096 NodeClaims in flight (one 400-vCPU pod each), then small pods that land on them: the in-place scan order
     spills from LDS into global memory."""
     zones, types = catalog776()
     big = [{"uid": "big-%05d" % i, "ns": "default", "creation_ts": 1700000000, "labels": {"app": "big"},
             "requests": {"cpu": 400000, "memory": 64 * wl.GI * 1000}} for i in range(4300)]
     small = wl.mixed_pods(600, 8, zones, families(types), prefix="small")
-    ro, rg = _check_wave(L, Problem(types, big + small, [wl.default_nodepool()]))
+    ro, rg = _check_wave(LW, Problem(types, big + small, [wl.default_nodepool()]))
     assert rg.res.n_claims > 4096
