@@ -35,7 +35,7 @@ def pmc_traffic(n_pods):
     """HBM bytes per k_solve launch on this workload, from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE, each
     its own run; gfx950 correction of MI355X_MICROARCH.md applied) -- counters cannot be read from inside the run.  None
     for any workload other than the one profiled."""
-    path = os.path.join(ROOT, "profiles", "r01d_k_solve_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r01f_k_solve_wave_pmc.json")
     if n_pods != 10000 or not os.path.exists(path):
         return None
     with open(path) as f:
@@ -183,7 +183,7 @@ def main():
                                    % args.pods, "replicas": world, "n_claims": int(rb.res.n_claims)},
             "breakdown_ms": {"host_compile": sum(compile_ms) / len(compile_ms), "prepass_kernels": sum(pre_ms) / len(pre_ms),
                              "k_solve": k_ms, "host_decode_truncate": sum(decode_ms) / len(decode_ms)},
-            "roofline": {"bound": "hbm", "kernel": "k_solve", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_solve_wave" if L.stats().wave_solves else "k_solve", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.pods),
                          "peak_measured_copy": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
                          "algorithmic_bytes_per_launch": alg_bytes,

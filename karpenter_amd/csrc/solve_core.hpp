@@ -43,8 +43,8 @@ constexpr int KG_MAXGP = 32;      // NodeClaims evaluated exactly per pass
 constexpr int KG_GP0 = 8;         // ... in the first pass over a chunk of the scan order
 constexpr int KG_ROWW = 64;       // requirement-value words of one claim row
 constexpr int KG_TWLDS = 16;      // option-mask words (<= 1024 instance types) for the tables staged in LDS
-constexpr int KG_SPV = 8;         // values per special key whose value->types rows are staged in LDS
-constexpr int KG_OFFROWS = 16;    // (zone, capacity-type) offering rows staged in LDS
+constexpr int KG_SPV = 16;        // values per special key whose value->types rows are staged in LDS
+constexpr int KG_OFFROWS = 32;    // (zone, capacity-type) offering rows staged in LDS
 constexpr uint32_t KG_NOIDX = 0xFFFFFFFFu;
 
 // requirement meta word
