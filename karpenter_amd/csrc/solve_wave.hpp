@@ -16,6 +16,12 @@
 
 namespace kg {
 
+// Keeps a uniform value in a VECTOR register: the kernel is bound by scalar registers (about 100 per wave, against the
+// ~90 sizes and pointers of DevProblem / SimState plus the loop state), and every scalar the compiler cannot hold is
+// spilled to a VGPR lane and reloaded with v_readlane; values that only feed vector instructions cost nothing as VGPRs.
+#define KG_VREG32(x) asm volatile("" : "+v"(x))
+#define KG_VREG64(x) asm volatile("" : "+v"(x))
+
 // Step 3-6 of NodeClaim.Add with the claim row in registers: lane a holds meta[a], lane i bits[i], lanes 8r the requests of
 // resource r, lane w word w of the option mask.  FRESH: the row is a NodeClaim just made from a template (every entry
 // counts as changed, template entries and the valid-type mask join the filter, hasOffering is always evaluated).
@@ -215,22 +221,24 @@ __device__ __forceinline__ uint64_t plain_set_or_all(uint32_t meta, uint64_t wor
 
 // scan order of the single-wave solve: one array, rotated in place (LDS while it fits, global memory beyond)
 constexpr uint32_t KG_WORD = 2 * KG_ORD;
-__device__ __forceinline__ unsigned long long word_get(const SimState& S, const Shared& sh, uint32_t p) {
-  if (p < KG_WORD) { unsigned long long v = (&sh.ord[0][0])[p]; KG_OPAQUE64(v); return v; }
+// (lds: every position in use is below KG_WORD -- a uniform fact the callers pass down, so that the common case has no
+// per-lane branch and no global load to wait for)
+__device__ __forceinline__ unsigned long long word_get(const SimState& S, const Shared& sh, bool lds, uint32_t p) {
+  if (lds || p < KG_WORD) { unsigned long long v = (&sh.ord[0][0])[lds ? (p & (KG_WORD - 1)) : p]; KG_OPAQUE64(v); return v; }
   return S.ordg[p];
 }
-__device__ __forceinline__ void word_set(const SimState& S, Shared& sh, uint32_t p, unsigned long long v) {
-  if (p < KG_WORD) (&sh.ord[0][0])[p] = v; else S.ordg[p] = v;
+__device__ __forceinline__ void word_set(const SimState& S, Shared& sh, bool lds, uint32_t p, unsigned long long v) {
+  if (lds || p < KG_WORD) (&sh.ord[0][0])[lds ? (p & (KG_WORD - 1)) : p] = v; else S.ordg[p] = v;
 }
 // end of the k-pod group: first position whose claim holds more than k pods (64-ary search)
-__device__ __forceinline__ uint32_t word_group_end(const SimState& S, const Shared& sh, uint32_t nclaims, uint32_t k, uint32_t lane) {
+__device__ __forceinline__ uint32_t word_group_end(const SimState& S, const Shared& sh, bool lds, uint32_t nclaims, uint32_t k, uint32_t lane) {
   uint32_t stride = 1;
   while ((unsigned long long)stride * 64 < nclaims) stride *= 64;
   uint32_t lo = 0;
   while (true) {
     const unsigned long long q = (unsigned long long)lo + (unsigned long long)lane * stride;
     bool f = true;
-    if (q < nclaims) f = (uint32_t)(word_get(S, sh, (uint32_t)q) >> 32) > k;
+    if (q < nclaims) f = (uint32_t)(word_get(S, sh, lds, (uint32_t)q) >> 32) > k;
     const unsigned long long b = __ballot(f);
     const uint32_t L = b ? (uint32_t)(__ffsll(b) - 1) : 64u;
     if (stride == 1) return lo + L;
@@ -333,7 +341,8 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
       have_q2 = false;
     }
     const uint32_t need = KG_UNI(pc.need);
-    const uint64_t tolw = KG_UNI64(pc.tolw), hp_conf = P.has_ports ? KG_UNI64(pc.vc.hp_conf) : 0ull;
+    uint64_t tolw = pc.tolw, hp_conf = P.has_ports ? pc.vc.hp_conf : 0ull;  // (uniform, but only vector instructions use them)
+    KG_VREG64(tolw); KG_VREG64(hp_conf);
     const bool hcok = KG_UNI(pc.vc.v.host_claim_ok) != 0;
     const uint32_t ne = KG_UNI(pc.vc.ne);
     // the pod's side of the prefilter record test
@@ -346,9 +355,11 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
       const uint64_t pw = plain_set_or_all(pm, KG_UNI64(pc.vc.ebits[pb]));
       if (spec == P.slot_zone) pzone = pw; else pct = pw;
     }
+    KG_VREG64(pzone); KG_VREG64(pct);
     last_c = KG_NOIDX; last_new = 0;
     uint32_t reason = 0;
     bool placed = false;
+    const bool lds = nclaims < KG_WORD;  // the scan order (with the claim this placement may add) fits LDS
     KG_W(0);
     // the pod's side of the prefilter, in vector registers (the same value in every lane)
     int64_t prq[4];
@@ -363,7 +374,7 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
       bool ok = false;
       unsigned long long oe = 0;
       if (pos < nclaims) {
-        oe = word_get(S, sh, pos);
+        oe = word_get(S, sh, lds, pos);
         const uint32_t c = (uint32_t)oe;
         // the claim's prefilter record: twelve 16-byte loads from consecutive addresses, one round trip
         const KG_GLOBAL uint4* rec = (const KG_GLOBAL uint4*)(S.c_row + (size_t)c * KG_ROW_WORDS);
@@ -404,7 +415,7 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         int64_t phd = 0;  // lanes 0..3: the headroom of resources 0..3
         if (lane < 4) phd = (int64_t)row[lane];
         const uint64_t w6_v = row[6], w7_v = row[7];
-        const uint32_t endk = word_group_end(S, sh, nclaims, wnp, lane);  // (LDS work under the row's round trip)
+        const uint32_t endk = word_group_end(S, sh, lds, nclaims, wnp, lane);  // (LDS work under the row's round trip)
         const uint64_t w6 = KG_UNI64(w6_v), w7 = KG_UNI64(w7_v);
         const uint32_t tm = (uint32_t)w6, stamp = (uint32_t)w7, hst = (uint32_t)(w7 >> 32);
         const int64_t req0 = req;
@@ -451,10 +462,10 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         for (uint32_t p0 = wpos; p0 + 1 < endk; p0 += 64) {
           const uint32_t p = p0 + lane;
           unsigned long long v = 0;
-          if (p + 1 < endk) v = word_get(S, sh, p + 1);
-          if (p + 1 < endk) word_set(S, sh, p, v);
+          if (p + 1 < endk) v = word_get(S, sh, lds, p + 1);
+          if (p + 1 < endk) word_set(S, sh, lds, p, v);
         }
-        if (lane == 0) word_set(S, sh, endk - 1, ((unsigned long long)(wnp + 1) << 32) | c);
+        if (lane == 0) word_set(S, sh, lds, endk - 1, ((unsigned long long)(wnp + 1) << 32) | c);
         last_c = c; last_new = 0; last_npods = wnp; last_stamp = stamp;
         seq += 1;
         placed = true;
@@ -480,7 +491,8 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
           }
         }
         if (__ballot(cm != 0) == 0) { reason |= 16u; continue; }  // all available instance types exceed limits
-        if (!((tolw >> t) & 1) || !hcok) { reason |= ((tolw >> t) & 1) ? 2u : 1u; continue; }
+        const bool tol_t = (KG_UNI64(tolw) >> t) & 1;
+        if (!tol_t || !hcok) { reason |= tol_t ? 2u : 1u; continue; }
         // NewNodeClaim: the template's requirements and daemon overhead
         uint32_t meta = 0;
         uint64_t bits = 0;
@@ -525,17 +537,17 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
           S.pod_index[pod_row(S, pod)] = (int32_t)c;
           if (P.has_ports) S.c_ports[c] = pc.vc.hp_use;
         }
-        const uint32_t endk = word_group_end(S, sh, nclaims, 1, lane);
+        const uint32_t endk = word_group_end(S, sh, lds, nclaims, 1, lane);
         // shift [endk, nclaims) right by one, from the top
         for (uint32_t hi = nclaims; hi > endk;) {
           const uint32_t lo2 = hi - endk > 64 ? hi - 64 : endk;
           const uint32_t p = lo2 + lane;
           unsigned long long v = 0;
-          if (p < hi) v = word_get(S, sh, p);
-          if (p < hi) word_set(S, sh, p + 1, v);
+          if (p < hi) v = word_get(S, sh, lds, p);
+          if (p < hi) word_set(S, sh, lds, p + 1, v);
           hi = lo2;
         }
-        if (lane == 0) word_set(S, sh, endk, (1ull << 32) | c);
+        if (lane == 0) word_set(S, sh, lds, endk, (1ull << 32) | c);
         last_c = c; last_new = 1;
         nclaims += 1; seq += 1;
         placed = true;
