@@ -129,9 +129,10 @@ __global__ void __launch_bounds__(NT) k_simulate(DevProblem Pin, const SimState*
 template <bool DBG>
 __global__ void __launch_bounds__(64) k_solve_wave(DevProblem Pin, const SimState* sims, const uint32_t* nqueue) {
   __shared__ Shared sh;
+  __shared__ uint64_t thr_lds[KG_THRROW_WORDS];
   const DevProblem& P = Pin;
   const SimState S = sims[blockIdx.x];
-  solve_wave<DBG>(P, S, sh, nqueue[blockIdx.x]);
+  solve_wave<DBG>(P, S, sh, thr_lds, nqueue[blockIdx.x]);
 }
 
 // k_sim_init: one workgroup per simulation copies the pristine state image into its slot and applies the patches

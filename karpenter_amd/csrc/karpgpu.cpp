@@ -1072,6 +1072,17 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
         pe.bits = 0xFFFF;
       }
     }
+    vc.pzone = vc.pct = ~0ull;
+    {
+      const int sz = spec_of_key(ctx->kZone), sc = spec_of_key(ctx->kCT);
+      for (uint32_t j = 0; j < vc.ne; ++j) {
+        const PodEntry& pe = vc.ent[j];
+        if (pe.spec < 0 || pe.bits == 0xFFFF || (pe.spec != sz && pe.spec != sc)) continue;
+        const uint64_t w = vc.ebits[pe.bits];
+        const uint64_t pw = ((pe.meta & (RM_PRESENT | RM_COMPL)) == RM_PRESENT && w != 0) ? w : ~0ull;
+        if (pe.spec == sz) vc.pzone = pw; else vc.pct = pw;
+      }
+    }
     if (vc.v.match_cnt > (uint32_t)KG_MAXLIST) throw Unsupported("pod consults more than 8 topology groups");
     vc.nlist = vc.v.match_cnt;
     for (uint32_t li = 0; li < vc.nlist; ++li) {

@@ -108,6 +108,7 @@ struct VariantCtx {
   Variant v;
   uint32_t ne, nlist;
   uint64_t hp_use, hp_conf;  // host ports the pod reserves / port ids that conflict with one of them (scheduling.HostPortUsage)
+  uint64_t pzone, pct;       // the pod's own zone / capacity-type sets when they are plain non-empty sets, else all ones (prefilter)
   PodEntry ent[KG_MAXE];
   ListX lst[KG_MAXLIST];
   uint64_t ebits[KG_EBITS];

@@ -26,9 +26,10 @@ namespace kg {
 // resource r, lane w word w of the option mask.  FRESH: the row is a NodeClaim just made from a template (every entry
 // counts as changed, template entries and the valid-type mask join the filter, hasOffering is always evaluated).
 // Returns "the option mask stays non-empty"; *compat = the requirement merge went through.
+constexpr uint32_t KG_THRROW_WORDS = 6144;  // fit-threshold rows ("types with allocatable >= v") staged in LDS by the single-wave solve: 48 KB
 template <bool FRESH>
-__device__ __forceinline__ bool wave_add(const DevProblem& P, const Shared& sh, const PodCtx& pc, uint32_t lane, uint32_t need, uint32_t tmpl, uint32_t& meta,
-                                         uint64_t& bits, int64_t& req, uint64_t& m, bool* compat) {
+__device__ __forceinline__ bool wave_add(const DevProblem& P, const Shared& sh, const uint64_t* thr_rows, const PodCtx& pc, uint32_t lane, uint32_t need, uint32_t tmpl,
+                                         uint32_t& meta, uint64_t& bits, int64_t& req, uint64_t& m, bool* compat) {
   const uint32_t NR = (uint32_t)P.R, TW = (uint32_t)P.TW;
   const uint32_t rg = lane >> 3;
   uint4 pe4;
@@ -108,12 +109,17 @@ __device__ __forceinline__ bool wave_add(const DevProblem& P, const Shared& sh, 
   }
   const unsigned long long useb = __ballot(ruse && (lane & 7) == 0);  // bit 8r: resource r decides
   if (__ballot(ruse && tidx >= tn) != 0) return false;                // a request above every instance type
-  const uint32_t trow = toff + (tidx < tn ? tidx : 0);
+  const uint32_t trow = toff + (tidx < tn ? tidx : 0), lrow = tbase + (tidx < tn ? tidx : 0);
   // ---- step 6: the instance-type filter on lanes [0, TW)
   const uint32_t w = lane < TW ? lane : 0;
   uint64_t tmk[KG_MAXR];
+  if (thr_rows) {
 #pragma unroll
-  for (int r = 0; r < KG_MAXR; ++r) tmk[r] = P.thr_mask[(size_t)rl32(trow, 8 * r) * TW + w];  // (unconditional: one round trip; row 0 for unused lanes)
+    for (int r = 0; r < KG_MAXR; ++r) { tmk[r] = thr_rows[rl32(lrow, 8 * r) * TW + w]; KG_OPAQUE64(tmk[r]); }  // (row 0 for unused lanes)
+  } else {
+#pragma unroll
+    for (int r = 0; r < KG_MAXR; ++r) tmk[r] = P.thr_mask[(size_t)rl32(trow, 8 * r) * TW + w];  // (unconditional: one round trip)
+  }
 #pragma unroll
   for (int r = 0; r < KG_MAXR; ++r) tmk[r] = ((useb >> (8 * r)) & 1) ? tmk[r] : ~0ull;
   for (uint32_t em = ent_changed & ent_ord; em; em &= em - 1) {
@@ -286,7 +292,7 @@ __device__ __forceinline__ void ctx_fetch_image(const DevProblem& P, PodCtx& nx,
 // nodes, no minValues, TW <= KG_TWLDS, every table stages into LDS, visit counters off.
 // DBG: with the per-section cycle accounting (its counters would otherwise cost the production kernel two dozen scalar registers)
 template <bool DBG>
-__device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& S, Shared& sh, uint32_t n_queue) {
+__device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& S, Shared& sh, uint64_t* thr_lds, uint32_t n_queue) {
   const uint32_t lane = threadIdx.x & 63;
   // cycle accounting per section of a placement (stats & 8; debug): registers, written once at the end
   constexpr bool WT = DBG;
@@ -298,6 +304,20 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
   const uint32_t Ka = (uint32_t)P.Ka, Wa = (uint32_t)P.Wa, NR = (uint32_t)P.R, TW = (uint32_t)P.TW, NP = (uint32_t)P.NP;
   const size_t Cmax = (size_t)P.Cmax;
   const uint32_t rg = lane >> 3;
+  // the fit-threshold rows of the active resources, in the order of sh.thr_val, when they fit
+  const uint64_t* thr_rows = nullptr;
+  {
+    uint32_t tot = 0;
+    for (uint32_t r = 0; r < NR; ++r) tot += sh.a_thr_n[r];
+    if (KG_UNI(tot) * TW <= KG_THRROW_WORDS) {
+      for (uint32_t r = 0; r < NR; ++r) {
+        const uint32_t n = KG_UNI(sh.a_thr_n[r]), b = KG_UNI(sh.thr_base[r]), o = KG_UNI(sh.a_thr_off[r]);
+        for (uint32_t i = lane; i < n * TW; i += 64) thr_lds[b * TW + i] = P.thr_mask[(size_t)o * TW + i];
+      }
+      thr_rows = thr_lds;
+      __syncthreads();
+    }
+  }
   const int zslot = P.slot_zone >= 0 ? (int)sh.spec_slot[P.slot_zone] : -1, cslot = P.slot_ct >= 0 ? (int)sh.spec_slot[P.slot_ct] : -1;
   const uint32_t zoff = zslot >= 0 ? (uint32_t)sh.aoff[zslot] : 0, coff = cslot >= 0 ? (uint32_t)sh.aoff[cslot] : 0;
   const uint32_t QCAP = S.qcap;
@@ -345,16 +365,8 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
     KG_VREG64(tolw); KG_VREG64(hp_conf);
     const bool hcok = KG_UNI(pc.vc.v.host_claim_ok) != 0;
     const uint32_t ne = KG_UNI(pc.vc.ne);
-    // the pod's side of the prefilter record test
-    uint64_t pzone = ~0ull, pct = ~0ull;
-    for (uint32_t j = 0; j < ne; ++j) {
-      const PodEntry pe = pc.vc.ent[j];
-      const int spec = (int)KG_UNI((uint32_t)(int)pe.spec);
-      const uint32_t pm = KG_UNI(pe.meta), pb = KG_UNI(pe.bits);
-      if (spec < 0 || pb == 0xFFFF || (spec != P.slot_zone && spec != P.slot_ct)) continue;
-      const uint64_t pw = plain_set_or_all(pm, KG_UNI64(pc.vc.ebits[pb]));
-      if (spec == P.slot_zone) pzone = pw; else pct = pw;
-    }
+    // the pod's side of the prefilter test (the sets were compiled on the host)
+    uint64_t pzone = pc.vc.pzone, pct = pc.vc.pct;
     KG_VREG64(pzone); KG_VREG64(pct);
     last_c = KG_NOIDX; last_new = 0;
     uint32_t reason = 0;
@@ -422,7 +434,7 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         uint64_t m = cm;
         bool compat = true;
         KG_W(2);
-        const bool feasible = wave_add<false>(P, sh, pc, lane, need, tm, meta, bits, req, m, &compat);
+        const bool feasible = wave_add<false>(P, sh, thr_rows, pc, lane, need, tm, meta, bits, req, m, &compat);
         KG_W(3);
         if (WT) wt[10] += 1;
         if (!feasible) {
@@ -506,7 +518,7 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         if (rg < NR) req = P.tmpl_req[(size_t)rg * NP + t];
         uint64_t m = cm;
         bool compat = true;
-        const bool feasible = wave_add<true>(P, sh, pc, lane, need, t, meta, bits, req, m, &compat);
+        const bool feasible = wave_add<true>(P, sh, thr_rows, pc, lane, need, t, meta, bits, req, m, &compat);
         if (!feasible) { reason |= compat ? 8u : 2u; continue; }
         // ---- commit the new claim: appended to the end of the one-pod group
         KG_GLOBAL uint64_t* row = S.c_row + (size_t)c * KG_ROW_WORDS;
