@@ -366,7 +366,11 @@ int32_t kg_destroy(kg_ctx* ctx);
 int32_t kg_last_error(kg_ctx* ctx, char* buf, size_t n);
 int32_t kg_stats_get(kg_ctx* ctx, kg_stats* out);
 /* kg_results.visited_* / algorithmic_bytes count the rows the REFERENCE algorithm visits.  Keeping them
- * exact costs one extra pass per placement; production callers switch it off (default: on). */
+ * exact costs one extra pass per placement; production callers switch it off (default: on; bit 0 of `enabled`).  With
+ * the counters off, a Solve without topology groups, existing nodes and minValues NodePools is served by the single-wave
+ * kernel (kg_stats.wave_solves counts them), every other one by the workgroup kernel: same results.  The other bits are
+ * debugging aids: 2 = phase timers to stderr, 4 / 8 = 1024 / 512 threads for the workgroup kernel, 16 = never use the
+ * wave-local / single-wave paths, 32 = per-wave cycle accounting to stderr. */
 int32_t kg_set_collect_stats(kg_ctx* ctx, int32_t enabled);
 /* "hip-gfx950" for the product library */
 const char* kg_backend(void);
