@@ -341,6 +341,9 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
     cur ^= 1;
     if (!have_ctx) ctx_fetch_image(P, sh.pcb[cur], lane, pod, variant);
     const PodCtx& pc = sh.pcb[cur];
+    // what the previous placement's lanes stored is read by other lanes from here on.  (Before the loads below are
+    // issued: the wait is for everything outstanding, and those loads are only needed when this placement is over.)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     // ---- start on the next pod: its queue entry (loaded one placement ago, or now), its context image and requests go to
     // registers now and to the other context buffer when this placement is over; the entry after it is requested as well
     const bool next_ok = qlen >= 1;
@@ -377,9 +380,6 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
     int64_t prq[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) prq[r] = pc.preq[r];
-    // what the previous placement's lanes stored is read by other lanes from here on: its stores have had the pop and
-    // the prefetch to complete in
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     // ---- in-flight NodeClaims in scan order, 64 positions per step
     for (uint32_t base = 0; base < nclaims && !placed; base += 64) {
       const uint32_t pos = base + lane;
