@@ -42,7 +42,7 @@ struct PodClass {
 
 struct PodRef {
   uint32_t cls;
-  std::vector<std::pair<uint32_t, int64_t>> requests;  // incl. pods:1
+  uint32_t rq_off = 0, rq_n = 0;  // requests (incl. pods:1): ParsedPods::rq[rq_off .. rq_off + rq_n) -- one pool, no allocation per pod
   std::string uid;
   int64_t creation;
   int node;
@@ -53,6 +53,7 @@ struct PodRef {
 struct ParsedPods {
   std::vector<PodClass> classes;
   std::vector<PodRef> pods;
+  std::vector<std::pair<uint32_t, int64_t>> rq;  // (resource id, milli) pairs of every pod's requests
 };
 
 void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out, bool add_pods_one);
