@@ -73,4 +73,5 @@ struct kg_cluster {
   kg_ctx* ctx;
   std::vector<kg::CNode> nodes;
   kg::ParsedPods bound;
+  mutable std::vector<uint32_t> bound_rank;  // place of every bound pod in the Queue order among the bound pods (computed at first use)
 };

@@ -806,14 +806,51 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     auto mem = [&](uint32_t i) { return preq[(size_t)i * R + rm]; };
     // (keys gathered into one contiguous array first: the comparator then touches 32 bytes per pod instead of three tables)
     struct QKey { int64_t cpu, mem, creation; uint32_t idx; };
-    std::vector<QKey> keys((size_t)P);
-    for (int p = 0; p < P; ++p) keys[p] = QKey{cpu((uint32_t)p), mem((uint32_t)p), PP.pods[p].creation, (uint32_t)p};
-    std::stable_sort(keys.begin(), keys.end(), [&](const QKey& a, const QKey& b) {
+    auto qless = [&](const QKey& a, const QKey& b) {
       if (a.cpu != b.cpu) return a.cpu > b.cpu;
       if (a.mem != b.mem) return a.mem > b.mem;
       if (a.creation != b.creation) return a.creation < b.creation;
       return PP.pods[a.idx].uid < PP.pods[b.idx].uid;
-    });
+    };
+    auto qkey = [&](uint32_t p) { return QKey{cpu(p), mem(p), PP.pods[p].creation, p}; };
+    std::vector<QKey> keys;
+    keys.reserve((size_t)P);
+    if (in.universe_bound && cl) {
+      // a universe of bound pods: their mutual order is a property of the cluster snapshot (ranked once per kg_cluster),
+      // so only the pending pods are sorted here and merged into the bound pods taken in rank order
+      const size_t nb = cl->bound.pods.size();
+      if (cl->bound_rank.size() != nb) {
+        std::vector<QKey> bk(nb);
+        for (size_t i = 0; i < nb; ++i) {
+          int64_t c = 0, m = 0;
+          const PodRef& pr = cl->bound.pods[i];
+          for (uint32_t k = pr.rq_off; k < pr.rq_off + pr.rq_n; ++k) { if (cl->bound.rq[k].first == ctx->rCPU) c = cl->bound.rq[k].second; if (cl->bound.rq[k].first == ctx->rMemory) m = cl->bound.rq[k].second; }
+          bk[i] = QKey{c, m, pr.creation, (uint32_t)i};
+        }
+        std::stable_sort(bk.begin(), bk.end(), [&](const QKey& a, const QKey& b) {
+          if (a.cpu != b.cpu) return a.cpu > b.cpu;
+          if (a.mem != b.mem) return a.mem > b.mem;
+          if (a.creation != b.creation) return a.creation < b.creation;
+          return cl->bound.pods[a.idx].uid < cl->bound.pods[b.idx].uid;
+        });
+        cl->bound_rank.assign(nb, 0);
+        for (size_t r = 0; r < nb; ++r) cl->bound_rank[bk[r].idx] = (uint32_t)r;
+      }
+      std::vector<uint32_t> at_rank(nb, UINT32_MAX);
+      std::vector<QKey> pend_keys, bound_keys;
+      for (int p = 0; p < P; ++p) {
+        const int32_t bi = (*in.universe_bound)[p];
+        if (bi >= 0) at_rank[cl->bound_rank[bi]] = (uint32_t)p; else pend_keys.push_back(qkey((uint32_t)p));
+      }
+      bound_keys.reserve((size_t)P);
+      for (size_t r = 0; r < nb; ++r) if (at_rank[r] != UINT32_MAX) bound_keys.push_back(qkey(at_rank[r]));
+      std::stable_sort(pend_keys.begin(), pend_keys.end(), qless);
+      keys.resize(pend_keys.size() + bound_keys.size());
+      std::merge(pend_keys.begin(), pend_keys.end(), bound_keys.begin(), bound_keys.end(), keys.begin(), qless);
+    } else {
+      for (int p = 0; p < P; ++p) keys.push_back(qkey((uint32_t)p));
+      std::stable_sort(keys.begin(), keys.end(), qless);
+    }
     for (int p = 0; p < P; ++p) queue0[p] = keys[p].idx;
   }
 
@@ -1843,6 +1880,8 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   *n_records = 0;
   if (device_ms) *device_ms = 0;
 
+  HostProf prof_;
+  KG_PROF("cons: pod universe");
   // ---- pod universe: pending pods, pods of deleting nodes, then the candidates' reschedulable pods in candidate order
   ParsedPods pend;
   parse_pods(ctx, pending, &pend, true);
@@ -1881,6 +1920,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   }
   cand_begin[n_used] = (uint32_t)U.pods.size();
 
+  KG_PROF("cons: units");
   // ---- units of this shard
   struct Unit { uint32_t id; uint32_t pod_lo, pod_hi; bool skip; };
   std::vector<Unit> units;
@@ -1905,6 +1945,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   if (live.empty()) return KG_OK;
   if (vout) multi = true;  // (the unit is a prefix: every candidate up to its id is taken out of the cluster)
 
+  KG_PROF("cons: compile_problem");
   // ---- compile once; every simulation shares the problem tables
   SolveInputs in{ctx, cat, cluster, nodepools, &U};
   in.sim_cmax = cmax;
@@ -1923,6 +1964,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   std::vector<int> ract(V.resources.size(), -1);
   for (int r = 0; r < R; ++r) ract[C->act_res[r]] = r;
 
+  KG_PROF("cons: prepass + batches");
   float ms_pre = 0;
   hal::launch_prepass(C->dp, C->pre, &ms_pre);
   double ms_total = ms_pre;
@@ -2041,6 +2083,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
     }
     return KG_OK;
   }
+  KG_PROF("cons: decisions");
   // ---- computeConsolidation's decision logic per simulation (prices are float64 catalog data: host side)
   const int spot = V.vals[ctx->kCT].find("spot"), od = V.vals[ctx->kCT].find("on-demand");
   std::unordered_map<std::string, int> type_by_name;
@@ -2162,6 +2205,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
       }
     }
   }
+  KG_PROF("cons: end");
   return KG_OK;
   KG_GUARD_END(ctx)
 }
