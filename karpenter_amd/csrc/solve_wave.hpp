@@ -195,12 +195,21 @@ __device__ __forceinline__ bool wave_add(const DevProblem& P, const Shared& sh, 
   return __ballot(lane < TW && m != 0) != 0;
 }
 
-// max over the set types of mask (word w in lane w) of tab[type], for the types' table row `tab`
-__device__ __forceinline__ int64_t wave_max_over_mask(const int64_t* tab, uint64_t mask, uint32_t TW, uint32_t lane) {
+// max over the set types of mask (word w in lane w) of tab[type], for the types' table row `tab` of T entries.
+// Every load is unconditional (clamped index, selected afterwards): sixteen independent loads, one round trip.
+__device__ __forceinline__ int64_t wave_max_over_mask(const int64_t* tab, uint64_t mask, uint32_t TW, uint32_t T, uint32_t lane) {
+  int64_t v[KG_TWLDS];
+#pragma unroll
+  for (int w = 0; w < KG_TWLDS; ++w) {
+    const uint32_t idx = ((uint32_t)w < TW ? (uint32_t)w : 0u) * 64 + lane;
+    v[w] = tab[idx < T ? idx : T - 1];
+  }
   int64_t mx = 0;
-  for (uint32_t w = 0; w < TW; ++w) {
-    const uint64_t mw = rl64(mask, w);
-    if ((mw >> lane) & 1) { const int64_t v = tab[w * 64 + lane]; mx = v > mx ? v : mx; }
+#pragma unroll
+  for (int w = 0; w < KG_TWLDS; ++w) {
+    const uint64_t mw = rl64(mask, (uint32_t)w);  // (zero beyond TW words)
+    const int64_t x = ((mw >> lane) & 1) ? v[w] : 0;
+    mx = x > mx ? x : mx;
   }
   return wave_max_i64(mx);
 }
@@ -441,7 +450,7 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
           if (hst != stamp) {
             // the prefilter let an infeasible claim through: recompute its headroom (its options changed since)
             for (uint32_t r = 0; r < NR && r < 4; ++r) {
-              const int64_t mx = wave_max_over_mask(P.alloc + (size_t)KG_UNI(sh.a_res[r]) * P.T, cm, TW, lane);
+              const int64_t mx = wave_max_over_mask(P.alloc + (size_t)KG_UNI(sh.a_res[r]) * P.T, cm, TW, (uint32_t)P.T, lane);
               const int64_t rq = (int64_t)rl64((uint64_t)req0, 8 * r);
               if (lane == 0) row[r] = (uint64_t)(mx - rq);
             }
@@ -535,12 +544,12 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
           if (lane >= 4 && lane < 8) row[lane] = v;
         }
         for (uint32_t r = 0; r < NR; ++r) {
-          const int64_t mx = wave_max_over_mask(P.alloc + (size_t)KG_UNI(sh.a_res[r]) * P.T, m, TW, lane);
+          const int64_t mx = wave_max_over_mask(P.alloc + (size_t)KG_UNI(sh.a_res[r]) * P.T, m, TW, (uint32_t)P.T, lane);
           const int64_t rq = (int64_t)rl64((uint64_t)req, 8 * r);
           if (lane == 0 && r < 4) row[r] = (uint64_t)(mx - rq);
           // subtractMax: the worst-case capacity of the remaining options is charged against the limits
           if (P.tmpl_has_limits[t] && P.tmpl_limit_res[(size_t)r * NP + t]) {
-            const int64_t cx = wave_max_over_mask(P.cap + (size_t)KG_UNI(sh.a_res[r]) * P.T, m, TW, lane);
+            const int64_t cx = wave_max_over_mask(P.cap + (size_t)KG_UNI(sh.a_res[r]) * P.T, m, TW, (uint32_t)P.T, lane);
             if (lane == 0) S.remaining[(size_t)r * NP + t] -= cx;
           }
         }
