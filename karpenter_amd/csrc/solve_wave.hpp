@@ -348,7 +348,7 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
     qhead = qhead + 1 == QCAP ? 0 : qhead + 1;
     qlen -= 1;
     cur ^= 1;
-    if (!have_ctx) ctx_fetch_image(P, sh.pcb[cur], lane, pod, variant);
+    if (__builtin_expect(!have_ctx, 0)) ctx_fetch_image(P, sh.pcb[cur], lane, pod, variant);
     const PodCtx& pc = sh.pcb[cur];
     // what the previous placement's lanes stored is read by other lanes from here on.  (Before the loads below are
     // issued: the wait is for everything outstanding, and those loads are only needed when this placement is over.)
@@ -446,7 +446,7 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         const bool feasible = wave_add<false>(P, sh, thr_rows, pc, lane, need, tm, meta, bits, req, m, &compat);
         KG_W(3);
         if (WT) wt[10] += 1;
-        if (!feasible) {
+        if (__builtin_expect(!feasible, 0)) {
           if (hst != stamp) {
             // the prefilter let an infeasible claim through: recompute its headroom (its options changed since)
             for (uint32_t r = 0; r < NR && r < 4; ++r) {
@@ -495,7 +495,7 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
     }
     if (!placed) KG_W(1);
     // ---- a new NodeClaim from each template in weight order
-    if (!placed && nclaims < (uint32_t)P.Cmax) {
+    if (__builtin_expect(!placed && nclaims < (uint32_t)P.Cmax, 0)) {
       const uint32_t c = nclaims;
       for (uint32_t t = 0; t < NP && !placed; ++t) {
         // filterByRemainingResources: types whose capacity fits what the NodePool's limits leave
@@ -575,7 +575,7 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
       }
     }
     KG_W(6);
-    if (!placed) {
+    if (__builtin_expect(!placed, 0)) {
       // ---- Preferences.Relax + Queue.Push (the push lands behind the entries already fetched: they were only fetched
       // when the queue held them)
       const int32_t vnext = (int32_t)KG_UNI((uint32_t)pc.vc.v.next);
