@@ -19,7 +19,6 @@ namespace kg {
 // Keeps a uniform value in a VECTOR register: the kernel is bound by scalar registers (about 100 per wave, against the
 // ~90 sizes and pointers of DevProblem / SimState plus the loop state), and every scalar the compiler cannot hold is
 // spilled to a VGPR lane and reloaded with v_readlane; values that only feed vector instructions cost nothing as VGPRs.
-#define KG_VREG32(x) asm volatile("" : "+v"(x))
 #define KG_VREG64(x) asm volatile("" : "+v"(x))
 
 // Step 3-6 of NodeClaim.Add with the claim row in registers: lane a holds meta[a], lane i bits[i], lanes 8r the requests of
@@ -263,26 +262,7 @@ __device__ __forceinline__ uint32_t word_group_end(const SimState& S, const Shar
   }
 }
 
-// one Queue.Pop's worth of pod context by one wave
-__device__ __forceinline__ void ctx_fetch_wave(const DevProblem& P, PodCtx& nx, uint32_t lane, uint32_t pod, uint32_t variant) {
-  const uint64_t* src = (const uint64_t*)(P.vctx + variant);
-  uint64_t* dst = (uint64_t*)&nx.vc;
-  for (uint32_t i = lane; i < sizeof(VariantCtx) / 8; i += 64) dst[i] = src[i];
-  int64_t rq = 0;
-  if (lane < (uint32_t)P.R) rq = P.preq[(size_t)pod * P.R + lane];
-  if (lane < KG_MAXR) nx.preq[lane] = rq;
-  const unsigned long long nb = __ballot(rq != 0);
-  const VariantCtx* gv = P.vctx + variant;
-  if (lane == 0) { nx.need = (uint32_t)nb; nx.tolw = P.tol_tmpl[gv->v.tolset]; }
-  if (lane < KG_TWLDS) nx.podmask[lane] = lane < (uint32_t)P.TW ? P.podmask[(size_t)variant * P.TW + lane] : 0;
-  const uint32_t ne = gv->ne;
-  for (uint32_t i = lane; i < KG_MAXE * KG_TWLDS; i += 64) {
-    const uint32_t j = i / KG_TWLDS, w = i % KG_TWLDS;
-    if (j < ne && w < (uint32_t)P.TW) nx.eam[j][w] = P.e_amask[(size_t)gv->ent[j].e * P.TW + w];
-  }
-}
-
-// the same from the contiguous image k_pod_ctx built (one level of loads)
+// one Queue.Pop's worth of pod context by one wave, from the contiguous image k_pod_ctx built (one level of loads)
 __device__ __forceinline__ void ctx_fetch_image(const DevProblem& P, PodCtx& nx, uint32_t lane, uint32_t pod, uint32_t variant) {
   const uint64_t* img = (const uint64_t*)(P.pctx + variant);
   uint64_t* dst = (uint64_t*)&nx;
@@ -376,7 +356,6 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
     uint64_t tolw = pc.tolw, hp_conf = P.has_ports ? pc.vc.hp_conf : 0ull;  // (uniform, but only vector instructions use them)
     KG_VREG64(tolw); KG_VREG64(hp_conf);
     const bool hcok = KG_UNI(pc.vc.v.host_claim_ok) != 0;
-    const uint32_t ne = KG_UNI(pc.vc.ne);
     // the pod's side of the prefilter test (the sets were compiled on the host)
     uint64_t pzone = pc.vc.pzone, pct = pc.vc.pct;
     KG_VREG64(pzone); KG_VREG64(pct);
