@@ -25,20 +25,23 @@ namespace kg {
 // resource r, lane w word w of the option mask.  FRESH: the row is a NodeClaim just made from a template (every entry
 // counts as changed, template entries and the valid-type mask join the filter, hasOffering is always evaluated).
 // Returns "the option mask stays non-empty"; *compat = the requirement merge went through.
+// what a lane needs of the small problem tables in every NodeClaim.Add: constant over the Solve, read from LDS once
+struct LaneTabs {
+  uint32_t spa, spoff;       // lane i < nspec: active slot of 1-word key i and its word offset in a claim row
+  uint32_t tn, tbase, toff;  // lanes [8r, 8r + 8): number of fit thresholds of resource r, their base in sh.thr_val, in the catalog
+};
 constexpr uint32_t KG_THRROW_WORDS = 6144;  // fit-threshold rows ("types with allocatable >= v") staged in LDS by the single-wave solve: 48 KB
 template <bool FRESH>
-__device__ __forceinline__ bool wave_add(const DevProblem& P, const Shared& sh, const uint64_t* thr_rows, const PodCtx& pc, uint32_t lane, uint32_t need, uint32_t tmpl,
-                                         uint32_t& meta, uint64_t& bits, int64_t& req, uint64_t& m, bool* compat) {
+__device__ __forceinline__ bool wave_add(const DevProblem& P, const Shared& sh, const uint64_t* thr_rows, const LaneTabs& lt, const PodCtx& pc, uint32_t lane, uint32_t need,
+                                         uint32_t tmpl, uint32_t& meta, uint64_t& bits, int64_t& req, uint64_t& m, bool* compat) {
   const uint32_t NR = (uint32_t)P.R, TW = (uint32_t)P.TW;
   const uint32_t rg = lane >> 3;
   uint4 pe4;
   pe4.x = pe4.y = pe4.z = pe4.w = 0;
   if (lane < KG_MAXE) pe4 = ((const uint4*)pc.vc.ent)[lane];
-  uint32_t spa = 0, spoff = 0;
-  if (lane < (uint32_t)P.nspec) { spa = sh.spec_slot[lane]; spoff = sh.aoff[spa]; }
-  uint32_t tn = 0, tbase = 0, toff = 0;
+  const uint32_t spa = lt.spa, spoff = lt.spoff, tn = lt.tn, tbase = lt.tbase, toff = lt.toff;
   int64_t add = 0;
-  if (rg < NR) { tn = sh.a_thr_n[rg]; tbase = sh.thr_base[rg]; toff = sh.a_thr_off[rg]; add = pc.preq[rg]; }
+  if (rg < NR) add = pc.preq[rg];
   const uint32_t ne = KG_UNI(pc.vc.ne);
   bool ok = true;
   // ---- step 3: the pod's requirement entries, one after the other (distinct keys)
@@ -307,6 +310,10 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
       __syncthreads();
     }
   }
+  LaneTabs lt;
+  lt.spa = lt.spoff = lt.tn = lt.tbase = lt.toff = 0;
+  if (lane < (uint32_t)P.nspec) { lt.spa = sh.spec_slot[lane]; lt.spoff = sh.aoff[lt.spa]; }
+  if (rg < NR) { lt.tn = sh.a_thr_n[rg]; lt.tbase = sh.thr_base[rg]; lt.toff = sh.a_thr_off[rg]; }
   const int zslot = P.slot_zone >= 0 ? (int)sh.spec_slot[P.slot_zone] : -1, cslot = P.slot_ct >= 0 ? (int)sh.spec_slot[P.slot_ct] : -1;
   const uint32_t zoff = zslot >= 0 ? (uint32_t)sh.aoff[zslot] : 0, coff = cslot >= 0 ? (uint32_t)sh.aoff[cslot] : 0;
   const uint32_t QCAP = S.qcap;
@@ -422,7 +429,7 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         uint64_t m = cm;
         bool compat = true;
         KG_W(2);
-        const bool feasible = wave_add<false>(P, sh, thr_rows, pc, lane, need, tm, meta, bits, req, m, &compat);
+        const bool feasible = wave_add<false>(P, sh, thr_rows, lt, pc, lane, need, tm, meta, bits, req, m, &compat);
         KG_W(3);
         if (WT) wt[10] += 1;
         if (__builtin_expect(!feasible, 0)) {
@@ -506,7 +513,7 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         if (rg < NR) req = P.tmpl_req[(size_t)rg * NP + t];
         uint64_t m = cm;
         bool compat = true;
-        const bool feasible = wave_add<true>(P, sh, thr_rows, pc, lane, need, t, meta, bits, req, m, &compat);
+        const bool feasible = wave_add<true>(P, sh, thr_rows, lt, pc, lane, need, t, meta, bits, req, m, &compat);
         if (!feasible) { reason |= compat ? 8u : 2u; continue; }
         // ---- commit the new claim: appended to the end of the one-pod group
         KG_GLOBAL uint64_t* row = S.c_row + (size_t)c * KG_ROW_WORDS;
