@@ -18,6 +18,23 @@ struct kg_ctx {
   int block_threads = 256;  // workgroup size of k_solve (256, 512 or 1024): 256 measured best (one wave per SIMD)
   bool collect_stats = true;  // maintain the reference-visit counters (exact; costs an extra pass per placement)
   std::mutex mu;
+  // Device buffers of finished solves, kept for the next one (a Solve needs three; hipMalloc / hipFree per call cost more
+  // than the kernels of a small batch).  Used under `mu` only.
+  std::vector<kg::DeviceBuffer> pool;
+  void* pool_take(size_t bytes, size_t* got) {
+    size_t best = SIZE_MAX;
+    for (size_t i = 0; i < pool.size(); ++i)
+      if (pool[i].bytes >= bytes && pool[i].bytes <= 4 * bytes + (1u << 20) && (best == SIZE_MAX || pool[i].bytes < pool[best].bytes)) best = i;
+    if (best != SIZE_MAX) { void* p = pool[best].ptr; *got = pool[best].bytes; pool.erase(pool.begin() + best); return p; }
+    *got = bytes;
+    return kg::hal::dmalloc(bytes);
+  }
+  void pool_give(void* p, size_t bytes) {
+    if (!p) return;
+    if (pool.size() >= 6) { kg::hal::dfree(pool.front().ptr); pool.erase(pool.begin()); }
+    pool.push_back(kg::DeviceBuffer{p, bytes});
+  }
+  ~kg_ctx() { for (auto& b : pool) kg::hal::dfree(b.ptr); }
   uint32_t kHostname, kZone, kCT, kZid, kNodePool, kInstanceType;
   uint32_t rCPU, rMemory, rPods;
 };

@@ -279,6 +279,7 @@ struct Compiled {
   DevProblem dp{};
   PrepassTables pre{};
   DeviceBuffer prob_dev, state_dev, sims_dev;
+  size_t prob_cap = 0, state_cap = 0, sims_cap = 0;  // real sizes of the (possibly pooled, larger) allocations
   SimState sim{};  // device pointers
   std::vector<uint8_t> state_image;
   size_t state_bytes = 0, state_init_bytes = 0;  // whole state slot / its initialised prefix (the only part uploaded for a Solve)
@@ -293,9 +294,10 @@ struct Compiled {
   size_t o_nreq, o_creq, o_chead, o_chstamp, o_cmask, o_cbits, o_cmeta, o_cnpods, o_ctmpl, o_order, o_remaining, o_gcount, o_gdom, o_gpos, o_hcount, o_hpos, o_queue,
       o_podkind, o_excl, o_podindex, o_podreason, o_scratch, o_ordg, o_header, o_counters, o_nqueue;
   ~Compiled() {
-    hal::dfree(prob_dev.ptr);
-    hal::dfree(state_dev.ptr);
-    hal::dfree(sims_dev.ptr);
+    // (back to the context's pool; every path that builds or drops a Compiled holds ctx->mu)
+    ctx->pool_give(prob_dev.ptr, prob_cap);
+    ctx->pool_give(state_dev.ptr, state_cap);
+    ctx->pool_give(sims_dev.ptr, sims_cap);
   }
 };
 
@@ -1164,7 +1166,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
                o_pctx = A.reserve_tail(sim_mode ? 8 : (size_t)std::max(NV, 1) * sizeof(PodCtx)), o_atab = A.reserve_tail(5 * KG_MAXR * 4),
                o_nlab = A.reserve_tail((size_t)std::max(S, 1) * NW * 8);
   C.prob_dev.bytes = A.total();
-  C.prob_dev.ptr = hal::dmalloc(C.prob_dev.bytes);
+  C.prob_dev.ptr = ctx->pool_take(C.prob_dev.bytes, &C.prob_cap);
   hal::h2d(C.prob_dev.ptr, A.bytes.data(), A.bytes.size());
   hal::dzero((uint8_t*)C.prob_dev.ptr + A.bytes.size(), C.prob_dev.bytes - A.bytes.size());
   auto dptr = [&](size_t off) { return (uint8_t*)C.prob_dev.ptr + off; };
@@ -1267,13 +1269,13 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   C.o_crow = C.state_bytes;
   if (sim_mode) return Cp;  // the caller lays out one slot per simulation
   C.state_dev.bytes = C.state_bytes + (C.wave_ok ? (size_t)Cmax * 896 : 8);  // claim rows of the single-wave solve (KG_ROW_WORDS * 8)
-  C.state_dev.ptr = hal::dmalloc(C.state_dev.bytes);
+  C.state_dev.ptr = ctx->pool_take(C.state_dev.bytes, &C.state_cap);
   hal::h2d(C.state_dev.ptr, C.state_image.data(), C.state_init_bytes);
   hal::dzero((uint8_t*)C.state_dev.ptr + C.state_init_bytes, C.state_bytes - C.state_init_bytes);
   C.sim = sim_at(C, (uint8_t*)C.state_dev.ptr);
   SimState& St = C.sim;
   C.sims_dev.bytes = sizeof(SimState);
-  C.sims_dev.ptr = hal::dmalloc(sizeof(SimState));
+  C.sims_dev.ptr = ctx->pool_take(sizeof(SimState), &C.sims_cap);
   hal::h2d(C.sims_dev.ptr, &St, sizeof(SimState));
   KG_PROF("end");
   return Cp;
