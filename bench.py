@@ -35,7 +35,7 @@ def pmc_traffic(n_pods):
     """HBM bytes per k_solve launch on this workload, from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE, each
     its own run; gfx950 correction of MI355X_MICROARCH.md applied) -- counters cannot be read from inside the run.  None
     for any workload other than the one profiled."""
-    path = os.path.join(ROOT, "profiles", "r01i_k_solve_wave_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r01j_k_solve_wave_pmc.json")
     if n_pods != 10000 or not os.path.exists(path):
         return None
     with open(path) as f:
