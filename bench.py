@@ -88,7 +88,7 @@ def bench_consolidation(args, L, hcat, types, zones, world, rank, barrier, dist,
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        units = (min(len(order), 100) - 1) if multi else len(order)
+        units = (min(len(order), 101) - 1) if multi else len(order)
         out["multi_node" if multi else "single_node"] = {
             "value": units * args.steps / dt, "unit": "prefixes/s" if multi else "candidates/s", "units_per_round": units,
             "ms_per_round": dt * 1e3 / args.steps, "device_ms_per_round_rank0": sum(dms) / len(dms),

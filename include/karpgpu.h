@@ -331,12 +331,14 @@ typedef struct {
 } kg_decision;
 
 /* per-candidate record (also the fixed-size record gathered across GPUs) */
+#define KG_RECORD_TYPE_WORDS 16
 typedef struct {
   int32_t candidate;         /* index in candidates[] (single) or `mid` = prefix length-1 (multi) */
   int32_t decision;          /* computeConsolidation's verdict for this unit, before first-wins / binary-search selection */
   uint32_t nodepool, n_types;
   double candidate_price;    /* getCandidatePrices: sum of the cheapest offering compatible with each candidate's labels */
-  uint64_t type_mask[13];    /* catalog types of the replacement (<= 832 types) after the price filters */
+  uint64_t type_mask[KG_RECORD_TYPE_WORDS]; /* catalog types of the replacement after the price filters (<= 1024 types: the limit of a
+                                               consolidation simulation's option mask; larger catalogs return KG_EUNSUPPORTED) */
   uint64_t zone_mask, ct_mask; /* replacement requirements on zone / capacity type as the library's value-id masks (opaque;
                                   kg_consolidate_select uses them to price-order the options) */
   uint8_t spot_only; uint8_t pad[7];
@@ -454,7 +456,7 @@ int32_t kg_consolidate_select(kg_ctx* ctx, kg_catalog* catalog, int32_t multi, c
                               uint32_t n_candidates, kg_decision* out);
 /* Validation re-simulation (Appendix A.9 "wait 15 s, recompute candidates, re-simulate, require the
  * same outcome"): the caller uploads a FRESH cluster snapshot and passes the command it is about to execute -- its
- * candidate nodes (indices into the fresh snapshot, at most 100), KG_DECISION_DELETE / _REPLACE and, for a replace, the
+ * candidate nodes (indices into the fresh snapshot, at most 101: the longest prefix the multi-node search probes), KG_DECISION_DELETE / _REPLACE and, for a replace, the
  * instance types it would launch.  *valid = 1 when every rescheduled pod still schedules and the simulation ends in the
  * same kind of outcome: no new NodeClaim for a delete; exactly one for a replace, whose (truncated) options still
  * contain every type of the command. */

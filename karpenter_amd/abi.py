@@ -46,7 +46,7 @@ CLAIM_OUT = np.dtype([("nodepool", "<u4"), ("n_pods", "<u4"), ("types", RANGE), 
 REQ_OUT = np.dtype([("key", "<u4"), ("complement", "u1"), ("has_gt", "u1"), ("has_lt", "u1"), ("gt", "<i8"), ("lt", "<i8"),
                     ("values", RANGE)], align=True)
 CANDIDATE_RECORD = np.dtype([("candidate", "<i4"), ("decision", "<i4"), ("nodepool", "<u4"), ("n_types", "<u4"),
-                             ("candidate_price", "<f8"), ("type_mask", "<u8", (13,)), ("zone_mask", "<u8"), ("ct_mask", "<u8"),
+                             ("candidate_price", "<f8"), ("type_mask", "<u8", (16,)), ("zone_mask", "<u8"), ("ct_mask", "<u8"),
                              ("spot_only", "u1"), ("pad", "u1", (7,))], align=True)
 EC2_DEVICE = np.dtype([("name", "<u4"), ("manufacturer", "<u4"), ("count", "<i8"), ("memory_mib", "<i8")], align=True)
 EC2_TYPE = np.dtype([("name", "<u4"), ("arch", "<u4"), ("first_arch_is_arm64", "u1"), ("hypervisor", "<u4"), ("cpu_manufacturer", "<u4"),

@@ -1910,7 +1910,9 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
     universe_bound.push_back((int32_t)bi);
   };
   std::vector<uint8_t> is_cand(cluster->nodes.size(), 0);
-  const uint32_t n_used = multi ? std::min<uint32_t>(n, 100) : n;
+  // multi: firstNConsolidationOption gets max = Clamp(len, 0, 100) and only lowers it to len - 1 when len <= max, so with more than
+  // 100 candidates the binary search probes mid in [1, 100] and the longest prefix is candidates[0:101]
+  const uint32_t n_used = multi ? std::min<uint32_t>(n, 101) : n;
   for (uint32_t i = 0; i < n_used; ++i) is_cand[cands->candidates[i]] = 1;
   for (size_t nd = 0; nd < cluster->nodes.size(); ++nd)
     if (cluster->nodes[nd].deleting && !is_cand[nd]) for (uint32_t bi : pods_of_node[nd]) add_bound(bi);
@@ -2202,7 +2204,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
       rec.zone_mask = rp.zmask;
       rec.ct_mask = rp.ctmask;
       for (uint32_t t : rp.types) {
-        if (t >= 13 * 64) throw Unsupported("more than 832 instance types in a consolidation record");
+        if (t >= KG_RECORD_TYPE_WORDS * 64) throw Unsupported("more than 1024 instance types in a consolidation record");
         rec.type_mask[t >> 6] |= 1ull << (t & 63);
       }
     }
@@ -2235,7 +2237,7 @@ int32_t kg_consolidate_validate(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
                                 const uint32_t* type_ids, uint32_t n_types, uint8_t* valid, double* device_ms) {
   if (!valid || (!candidates && n_candidates) || (!type_ids && n_types)) return KG_EINVAL;
   *valid = 0;
-  if (n_candidates == 0 || n_candidates > 100 || decision == KG_DECISION_NOOP) return KG_EINVAL;
+  if (n_candidates == 0 || n_candidates > 101 || decision == KG_DECISION_NOOP) return KG_EINVAL;
   kg_candidates_desc cd{};
   cd.candidates = candidates; cd.n_candidates = n_candidates; cd.shard = 0; cd.n_shards = 1;
   kg_candidate_record rec;
@@ -2269,7 +2271,7 @@ int32_t kg_consolidate_select(kg_ctx* ctx, kg_catalog* catalog, int32_t multi, c
   } else if (n_candidates >= 2) {
     std::unordered_map<int, const kg_candidate_record*> by_mid;
     for (uint32_t i = 0; i < n_records; ++i) by_mid[records[i].candidate] = &records[i];
-    int mn = 1, mx = (int)std::min<uint32_t>(n_candidates, 100) - 1;
+    int mn = 1, mx = (int)std::min<uint32_t>(n_candidates, 101) - 1;  // (max = 100 unless len <= 100: then len - 1)
     while (mn <= mx) {
       const int mid = (mn + mx) / 2;
       auto f = by_mid.find(mid);
@@ -2288,7 +2290,7 @@ int32_t kg_consolidate_select(kg_ctx* ctx, kg_catalog* catalog, int32_t multi, c
   out->device_ms = 0;
   if (win && win->decision == KG_DECISION_REPLACE) {
     std::vector<uint32_t> types;
-    for (int w = 0; w < 13; ++w)
+    for (int w = 0; w < KG_RECORD_TYPE_WORDS; ++w)
       for (uint64_t m = win->type_mask[w]; m; m &= m - 1) types.push_back((uint32_t)(w * 64 + __builtin_ctzll(m)));
     for (uint32_t t : types) check(t < catalog->types.size(), "record type id outside the catalog");
     order_by_price(catalog, &types, win->zone_mask, win->ct_mask);

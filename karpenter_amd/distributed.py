@@ -37,6 +37,6 @@ def consolidate(L, hcat, hcl, pending, nodepools, order, multi, spot_to_spot=Fal
     rank = dist.get_rank() if dist.is_initialized() else 0
     cd = abi.build_candidates(order, spot_to_spot=spot_to_spot, shard=rank, n_shards=world)
     local, dms = L.consolidate_records([hcat], hcl, pending, nodepools, cd, multi)
-    n_units = (min(len(order), 100) - 1 if multi else len(order)) if len(order) else 0
+    n_units = (min(len(order), 101) - 1 if multi else len(order)) if len(order) else 0
     allrec = gather_records(local, max(n_units, 1), device)
     return L.consolidate_select(hcat, allrec, len(order), multi), len(local), dms

@@ -1457,7 +1457,7 @@ static void fillRecord(const Outcome& o, int unit, kg_candidate_record* r) {
   r->n_types = (uint32_t)o.options.size();
   r->candidate_price = o.candidatePrice;
   r->spot_only = o.spotOnly;
-  for (auto* it : o.options) if (it->index < 13 * 64) r->type_mask[it->index >> 6] |= 1ull << (it->index & 63);
+  for (auto* it : o.options) if (it->index < KG_RECORD_TYPE_WORDS * 64) r->type_mask[it->index >> 6] |= 1ull << (it->index & 63);
 }
 static void fillDecision(const Outcome& o, int nCands, int first, uint64_t sims, kg_decision* d) {
   d->decision = o.decision;
@@ -1581,7 +1581,7 @@ int32_t ko_consolidate_records(const kg_catalog_desc* const* catalogs, uint32_t 
     auto pr = buildProblem(catalogs, n_catalogs, cluster, pending, nodepools);
     auto t0 = std::chrono::steady_clock::now();
     const uint32_t n = cands->n_candidates;
-    const uint32_t lo = multi ? 1 : 0, hi = multi ? std::min<uint32_t>(n, 100) : n;  // multi: mid in [1, min(n,100)-1]
+    const uint32_t lo = multi ? 1 : 0, hi = multi ? std::min<uint32_t>(n, 101) : n;  // multi: mid in [1, len <= 100 ? len - 1 : 100]
     const int shards = std::max(cands->n_shards, 1);
     uint32_t k = 0;
     uint64_t sims = 0;
@@ -1651,7 +1651,8 @@ int32_t ko_consolidate_decide(const kg_catalog_desc* const* catalogs, uint32_t n
       Outcome last;
       int lastN = 0;
       if (n >= 2) {
-        int mn = 1, mx = (int)std::min<uint32_t>(n, 100) - 1;
+        // max = Clamp(len, 0, 100); if len <= max { max = len - 1 }: with more than 100 candidates mid ranges over [1, 100]
+        int mn = 1, mx = n <= 100 ? (int)n - 1 : 100;
         while (mn <= mx) {
           const int mid = (mn + mx) / 2;
           Outcome o = evaluateUnit(*pr, cands, true, (uint32_t)mid, &sims);

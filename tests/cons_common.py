@@ -165,7 +165,7 @@ def check_validate(L, n=90):
                 continue
             n_cmd += 1
             cands = [order[int(r["candidate"])]]
-            tids = [w * 64 + b for w in range(13) for b in range(64) if (int(r["type_mask"][w]) >> b) & 1]
+            tids = [w * 64 + b for w in range(16) for b in range(64) if (int(r["type_mask"][w]) >> b) & 1]
             for snap, hsnap in ((cl, hcl), (cl_b, hcl_b)):
                 for d, t in ((dec, tids), (3 - dec, tids if dec == 1 else []), (2, [0, 1, 2])):
                     if d == 2 and not t:
@@ -189,4 +189,62 @@ def check_validate(L, n=90):
     finally:
         L.dll.kg_cluster_free(hcl)
         L.dll.kg_cluster_free(hcl_b)
+        L.dll.kg_catalog_free(hcat)
+
+
+def upstream_first_n(decisions, n):
+    """MultiNodeConsolidation.firstNConsolidationOption replayed by hand over per-prefix verdicts (decisions[mid] = the
+    command for candidates[0:mid+1] is not a no-op): max = Clamp(len, 0, 100); if len <= max: max = len - 1; binary search
+    over mid in [1, max] -> number of candidates of the last saved command (0 = none)."""
+    if n < 2:
+        return 0
+    lo, hi = 1, min(max(n, 0), 100)
+    if n <= hi:
+        hi = n - 1
+    last = 0
+    while lo <= hi:
+        mid = (lo + hi) // 2
+        if decisions[mid]:
+            last, lo = mid + 1, mid + 1
+        else:
+            hi = mid - 1
+    return last
+
+
+def check_multi_over_100(L, n=140):
+    """More than 100 candidates: the binary search runs over mid in [1, 100], so the longest command consolidates
+    candidates[0:101] -- 101 nodes (upstream passes max = 100 and only lowers it to len - 1 when len <= 100).  A sparse cluster
+    whose every prefix can be deleted must come back with 101 candidates; the records must hold prefix units 1..100; a
+    101-candidate command validates and a 102-candidate one is rejected as malformed."""
+    zones, types = catalog776()
+    nodes, bound = wl.existing_cluster(n, 11, types, zones, pods_lambda=2.0, util=0.1)
+    order = wl.disruption_order(nodes, bound)
+    cat, cl = abi.build_catalog(types), abi.build_cluster(nodes, bound)
+    pend, nps = abi.build_pods([]), abi.build_nodepools([wl.default_nodepool()], wl.WELL_KNOWN_LABELS)
+    hcat, hcl = L.catalog_upload(cat), L.cluster_upload(cl)
+    try:
+        cd = abi.build_candidates(order)
+        recs, _ = L.consolidate_records([hcat], hcl, pend, nps, cd, True)
+        assert [int(r["candidate"]) for r in recs] == list(range(1, 101))
+        st, ro, _ = loader.consolidate_records([cat], cl, pend, nps, cd, True)
+        assert st == 0 and [abi.record_tuple(r) for r in ro] == [abi.record_tuple(r) for r in recs]
+        verdict = {int(r["candidate"]): int(r["decision"]) != 0 for r in recs}
+        want = upstream_first_n(verdict, len(order))
+        dg = L.consolidate_select(hcat, recs, len(order), True)
+        st, do = loader.consolidate_decide([cat], cl, pend, nps, cd, True)
+        assert st == 0 and do["n_candidates"] == dg["n_candidates"] == want and do["decision"] == dg["decision"]
+        assert want == 101 and dg["decision"] == abi.DECISION_DELETE  # every prefix of this cluster fits on the remaining nodes
+        assert L.consolidate_validate([hcat], hcl, pend, nps, order[:101], dg["decision"], [])
+        with __import__("pytest").raises(Exception):
+            L.consolidate_validate([hcat], hcl, pend, nps, order[:102], dg["decision"], [])
+        # exactly 100 and 101 candidates: max = len - 1 = 99, and max = 100
+        for k, longest in ((100, 100), (101, 101)):
+            cdk = abi.build_candidates(order[:k])
+            rk, _ = L.consolidate_records([hcat], hcl, pend, nps, cdk, True)
+            assert [int(r["candidate"]) for r in rk] == list(range(1, longest))
+            dk = L.consolidate_select(hcat, rk, k, True)
+            st, ok = loader.consolidate_decide([cat], cl, pend, nps, cdk, True)
+            assert st == 0 and dk["n_candidates"] == ok["n_candidates"] == upstream_first_n({int(r["candidate"]): int(r["decision"]) != 0 for r in rk}, k)
+    finally:
+        L.dll.kg_cluster_free(hcl)
         L.dll.kg_catalog_free(hcat)

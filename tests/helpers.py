@@ -56,6 +56,21 @@ def full_size_problem(name):
     raise KeyError(name)
 
 
+def c4_full():
+    """BASELINE.json config 4 at full size: 5 000 existing nodes (seed 11), ~12 bound pods each at ~35 %
+    utilisation, 0 pending pods, 1 NodePool -> (types, nodes, bound, candidate order)."""
+    zones, types = catalog776()
+    nodes, bound = wl.existing_cluster(5000, 11, types, zones)
+    return types, nodes, bound, wl.disruption_order(nodes, bound)
+
+
+def records_digest(records):
+    """sha256 over the comparable part of kg_candidate_record rows (abi.record_tuple), in unit order."""
+    import hashlib
+    import json
+    return hashlib.sha256(json.dumps([abi.record_tuple(r) for r in records], separators=(",", ":")).encode()).hexdigest()
+
+
 def _with_host_ports(pods, seed, every=3):
     """Gives every `every`-th pod one or two host ports out of a small set (wildcard and specific ips, tcp / udp), so
     that conflicts (same port + protocol, equal ips or either 0.0.0.0) decide placements."""
@@ -103,13 +118,214 @@ class Problem:
 
 
 def c5_nodepools():
-    """C5: four weighted NodePools, the two heaviest with cpu limits (scaled)."""
-    return [wl.default_nodepool("np-a", weight=100, limits={"cpu": 200000}), wl.default_nodepool("np-b", weight=50, limits={"cpu": 1000000}),
+    """C5: four weighted NodePools {100, 50, 10, 0}, the two heaviest with cpu limits of 2 000 and 10 000 cores."""
+    return [wl.default_nodepool("np-a", weight=100, limits={"cpu": 2000000}), wl.default_nodepool("np-b", weight=50, limits={"cpu": 10000000}),
             wl.default_nodepool("np-c", weight=10), wl.default_nodepool("np-d", weight=0)]
+
+
+# parity scenarios for the scheduler features beyond the BASELINE shapes (Preferences.Relax steps, minDomains, daemon
+# overhead, node taints / tolerations, capacity-type spread, pod affinity, OR-ed node-affinity terms, negative operators)
+FEATURE_SCENARIOS = ["schedule_anyway", "prefer_no_schedule", "preferred_pod_affinity", "min_domains", "daemon_overhead", "node_taints",
+                     "ct_spread", "pod_affinity", "two_required_terms", "negative_selectors", "relax_everything"]
+
+
+def _pod(uid, cpu, mem_gi, app, ts=1700000000, **kw):
+    p = {"uid": uid, "ns": "default", "creation_ts": ts, "labels": {"app": app}, "requests": {"cpu": cpu, "memory": mem_gi * wl.GI * 1000}}
+    p.update(kw)
+    return p
+
+
+def feature_scenario(name):
+    zones, types = catalog776()
+    fams = families(types)
+    G = wl.G
+    if name == "schedule_anyway":
+        # NodePool "a-only" serves zone a; "rest" serves b / c but is tainted.  A ScheduleAnyway zone spread (maxSkew 1) lets the
+        # first replica of each app into zone a; the second cannot keep the skew there, cannot reach b / c, and drops the
+        # constraint (Preferences.Relax step 5) to land in zone a after all.  A DoNotSchedule twin stays unschedulable.
+        a_only = wl.default_nodepool("a-only", weight=10, extra_reqs=[(wl.L_ZONE, "In", [zones[0]])])
+        rest = wl.default_nodepool("rest", extra_reqs=[(wl.L_ZONE, "In", zones[1:])])
+        rest["taints"] = [("team", "other", "NoSchedule")]
+        pods = []
+        for d in range(6):
+            app = "any-%d" % d
+            sel = {"match_labels": {"app": app}}
+            when = "ScheduleAnyway" if d % 3 else "DoNotSchedule"
+            spreads = [{"key": wl.L_ZONE, "max_skew": 1, "when": when, "selector": sel}]
+            if d % 2:
+                spreads.append({"key": wl.L_HOSTNAME, "max_skew": 2, "when": "ScheduleAnyway", "selector": sel})
+            for k in range(7):
+                pods.append(_pod("%s-%02d" % (app, k), [250, 500, 1000][d % 3], 1 + d % 2, app, ts=1700000000 + d, spreads=spreads))
+        return Problem(types, pods + wl.mixed_pods(60, 17, zones, fams), [rest, a_only])
+    if name == "prefer_no_schedule":
+        # the heavier NodePool carries a PreferNoSchedule taint: pods that do not tolerate it go to the lighter pool while it
+        # has room under its limit, then fail, gain the toleration (Relax step 6) and use the tainted pool
+        soft = wl.default_nodepool("soft", weight=50)
+        soft["taints"] = [("maintenance", "soon", "PreferNoSchedule")]
+        plain = wl.default_nodepool("plain", weight=10, limits={"cpu": 40000})
+        pods = wl.mixed_pods(300, 23, zones, fams)
+        for i, p in enumerate(pods):
+            if i % 5 == 0:
+                p["tolerations"] = [("maintenance", "Equal", "soon", "PreferNoSchedule")]
+            elif i % 7 == 0:
+                p["tolerations"] = [(None, "Exists", None, None)]
+            elif i % 11 == 0:
+                p["tolerations"] = [("maintenance", "Exists", None, "NoSchedule")]  # wrong effect: does not help
+        return Problem(types, pods, [soft, plain])
+    if name == "preferred_pod_affinity":
+        # preferred pod affinity towards an app that does not exist (dropped first), preferred hostname anti-affinity among the
+        # replicas that a cpu limit cannot honour for all of them (dropped once the NodePool runs out), weights decide the order
+        pool = wl.default_nodepool(limits={"cpu": 2000000})
+        pods = []
+        for d in range(4):
+            app = "pref-%d" % d
+            sel = {"match_labels": {"app": app}}
+            ghost = {"match_labels": {"app": "ghost-%d" % (d % 2)}}
+            for k in range(12):
+                p = _pod("%s-%02d" % (app, k), 500, 1, app, ts=1700000000 + d)
+                p["affinity_preferred"] = [{"key": wl.L_ZONE, "selector": ghost, "weight": 10 + d}]
+                if d % 2 == 0:
+                    p["affinity_preferred"].append({"key": wl.L_HOSTNAME, "selector": ghost, "weight": 90})
+                p["anti_affinity_preferred"] = [{"key": wl.L_HOSTNAME, "selector": sel, "weight": 50}]
+                if d == 3:
+                    p["anti_affinity_preferred"].append({"key": wl.L_ZONE, "selector": sel, "weight": 70})
+                pods.append(p)
+        return Problem(types, pods + wl.mixed_pods(40, 29, zones, fams), [pool])
+    if name == "min_domains":
+        # minDomains above the number of zones: the global minimum counts as 0, so every zone takes maxSkew replicas and the
+        # rest stay pending; minDomains the zones do meet behaves like a plain spread
+        pods = []
+        for d, (md, skew) in enumerate(((4, 1), (3, 1), (5, 2), (2, 1), (None, 1))):
+            app = "md-%d" % d
+            sel = {"match_labels": {"app": app}}
+            for k in range(9):
+                pods.append(_pod("%s-%02d" % (app, k), 500, 2, app, ts=1700000000 + d,
+                                 spreads=[{"key": wl.L_ZONE, "max_skew": skew, "min_domains": md, "when": "DoNotSchedule", "selector": sel}]))
+        return Problem(types, pods, [wl.default_nodepool()])
+    if name == "daemon_overhead":
+        # daemonset requests: NodePool daemon overhead on every new NodeClaim (cpu, memory, pods and a resource no pod asks
+        # for), remaining daemon requests on existing nodes
+        heavy = wl.default_nodepool("heavy", weight=10)
+        heavy["daemon_overhead"] = {"cpu": 1500, "memory": 3 * wl.GI * 1000, "pods": 4000, "ephemeral-storage": 2 * wl.GI * 1000}
+        light = wl.default_nodepool("light", extra_reqs=[(G + "/instance-category", "In", ["c", "m"])])
+        light["daemon_overhead"] = {"cpu": 200, "memory": 256 * wl.MI * 1000, "pods": 2000}
+        nodes, bound = wl.existing_cluster(80, 31, types, zones, nodepool="heavy")
+        for i, nd in enumerate(nodes):
+            if i % 2 == 0:
+                nd["daemon_requests"] = {"cpu": 300 + 100 * (i % 5), "memory": 512 * wl.MI * 1000, "pods": 1000}
+        pods = wl.mixed_pods(500, 37, zones, fams)
+        for i, p in enumerate(pods):
+            if i % 4 == 0:
+                p["node_selector"] = dict(p.get("node_selector") or {}, **{wl.L_NODEPOOL: "light" if i % 8 else "heavy"})
+        return Problem(types, pods, [heavy, light], nodes=nodes, bound=bound)
+    if name == "node_taints":
+        # tainted existing nodes (NoSchedule / NoExecute / PreferNoSchedule, with and without values) against Equal / Exists
+        # tolerations with and without key and effect; a tainted NodePool next to a plain one
+        nodes, bound = wl.existing_cluster(150, 41, types, zones)
+        taints = [[("dedicated", "gpu", "NoSchedule")], [("dedicated", "batch", "NoSchedule")], [("evict", "", "NoExecute")],
+                  [("dedicated", "gpu", "NoSchedule"), ("evict", "", "NoExecute")], [("soft", "x", "PreferNoSchedule")], []]
+        for i, nd in enumerate(nodes):
+            nd["taints"] = taints[i % len(taints)]
+        tols = [[("dedicated", "Equal", "gpu", "NoSchedule")], [("dedicated", "Exists", None, None)], [(None, "Exists", None, None)],
+                [("evict", "Exists", None, "NoExecute")], [("dedicated", "Equal", "gpu", None), ("evict", "Equal", "", "NoExecute")],
+                [("dedicated", "Equal", "batch", "NoExecute")], [(None, "Exists", None, "NoSchedule")], []]
+        pods = wl.mixed_pods(600, 43, zones, fams)
+        for i, p in enumerate(pods):
+            p["tolerations"] = tols[i % len(tols)]
+        tainted = wl.default_nodepool("tainted", weight=10)
+        tainted["taints"] = [("dedicated", "batch", "NoSchedule")]
+        return Problem(types, pods, [tainted, wl.default_nodepool()], nodes=nodes, bound=bound)
+    if name == "ct_spread":
+        # topology spread over capacity types (scheduling.md:370-373), alone and together with a zone spread
+        pods = []
+        for d in range(5):
+            app = "ct-%d" % d
+            sel = {"match_labels": {"app": app}}
+            spreads = [{"key": wl.L_CT, "max_skew": 1 + d % 2, "when": "DoNotSchedule", "selector": sel}]
+            if d >= 3:
+                spreads.append({"key": wl.L_ZONE, "max_skew": 1, "when": "DoNotSchedule", "selector": sel})
+            for k in range(10):
+                p = _pod("%s-%02d" % (app, k), [500, 1000, 2000][d % 3], 2, app, ts=1700000000 + d, spreads=spreads)
+                if d == 2 and k % 2:
+                    p["node_selector"] = {wl.L_CT: "on-demand"}
+                pods.append(p)
+        return Problem(types, pods + wl.mixed_pods(50, 47, zones, fams), [wl.default_nodepool()])
+    if name == "pod_affinity":
+        # required pod affinity in a provisioning Solve: self-selecting replicas bootstrap one zone / one node and follow it;
+        # followers of another app land where that app went; followers of nobody stay pending; anti-affinity to a peer app
+        # on the zone key keeps two apps apart
+        pods = []
+        for d in range(3):
+            app = "herd-%d" % d
+            sel = {"match_labels": {"app": app}}
+            key = wl.L_ZONE if d != 1 else wl.L_HOSTNAME
+            for k in range(8):
+                pods.append(_pod("%s-%02d" % (app, k), 500 if d != 1 else 250, 1, app, ts=1700000000 + d, affinity_required=[{"key": key, "selector": sel}]))
+        for k in range(6):
+            pods.append(_pod("follow-%02d" % k, 250, 1, "follow", ts=1700000100, affinity_required=[{"key": wl.L_ZONE, "selector": {"match_labels": {"app": "herd-0"}}}]))
+        for k in range(3):
+            pods.append(_pod("lost-%02d" % k, 250, 1, "lost", ts=1700000200, affinity_required=[{"key": wl.L_ZONE, "selector": {"match_labels": {"app": "nobody"}}}]))
+        for k in range(6):
+            pods.append(_pod("apart-%02d" % k, 2000, 4, "apart", ts=1700000300,
+                             anti_affinity_required=[{"key": wl.L_ZONE, "selector": {"match_labels": {"app": "herd-2"}}}]))
+        return Problem(types, pods + wl.mixed_pods(40, 53, zones, fams), [wl.default_nodepool()])
+    if name == "two_required_terms":
+        # nodeSelectorTerms are OR-ed: the first term is tried, Relax drops it when nothing satisfies it (step 1); three
+        # terms relax twice; a satisfiable first term never looks at the second
+        pods = wl.mixed_pods(240, 59, zones, fams)
+        for i, p in enumerate(pods):
+            p.pop("required_terms", None)
+            if i % 3 == 0:
+                p["required_terms"] = [[(G + "/instance-family", "In", ["nosuch"])], [(G + "/instance-family", "In", ["m5", "c5", "r5"])]]
+            elif i % 3 == 1:
+                p["required_terms"] = [[(G + "/instance-category", "In", ["c"]), (G + "/instance-generation", "Gt", ["5"])],
+                                       [(G + "/instance-category", "In", ["zz"])]]
+            elif i % 9 == 2:
+                p["required_terms"] = [[(wl.L_ZONE, "In", ["mars-1a"])], [(G + "/instance-cpu", "In", ["3"])], [(wl.L_ARCH, "In", ["arm64"])]]
+        return Problem(types, pods, [wl.default_nodepool()])
+    if name == "negative_selectors":
+        # NotIn / DoesNotExist / Exists / Lt (and Gt) in node-affinity terms, on keys every type defines, keys only some
+        # types define (gpu / local nvme) and a key no type defines
+        pods = wl.mixed_pods(360, 61, zones, fams)
+        terms = [[(G + "/instance-family", "NotIn", ["m5", "c5", "t3", "t3a"])],
+                 [(G + "/instance-gpu-name", "DoesNotExist", [])],
+                 [(G + "/instance-local-nvme", "Exists", [])],
+                 [(G + "/instance-cpu", "Lt", ["9"]), (G + "/instance-cpu", "Gt", ["1"])],
+                 [(wl.L_ZONE, "NotIn", [zones[1]])],
+                 [(G + "/instance-generation", "Lt", ["6"]), (G + "/instance-category", "NotIn", ["t"])],
+                 [("example.com/team", "DoesNotExist", [])],
+                 [(wl.L_CT, "NotIn", ["spot"])],
+                 [(G + "/instance-local-nvme", "Gt", ["500"])],
+                 [(G + "/instance-memory", "Lt", ["16385"]), (wl.L_ARCH, "NotIn", ["arm64"])]]
+        for i, p in enumerate(pods):
+            p.pop("required_terms", None)
+            if i % 2 == 0:
+                p["required_terms"] = [terms[(i // 2) % len(terms)]]
+        return Problem(types, pods, [wl.default_nodepool()])
+    if name == "relax_everything":
+        # one pod class walks the whole Preferences.Relax ladder: two required terms, preferred pod affinity and
+        # anti-affinity, two preferred node-affinity terms, a ScheduleAnyway spread, a PreferNoSchedule NodePool
+        soft = wl.default_nodepool("soft")
+        soft["taints"] = [("soft", "yes", "PreferNoSchedule")]
+        pods = []
+        for k in range(10):
+            app = "ladder"
+            sel = {"match_labels": {"app": app}}
+            p = _pod("ladder-%02d" % k, 1000, 2, app)
+            p["required_terms"] = [[(G + "/instance-family", "In", ["nosuch"])], [(G + "/instance-category", "In", ["m", "c"])]]
+            p["affinity_preferred"] = [{"key": wl.L_ZONE, "selector": {"match_labels": {"app": "ghost"}}, "weight": 5}]
+            p["anti_affinity_preferred"] = [{"key": wl.L_ZONE, "selector": sel, "weight": 5}]
+            p["preferred_terms"] = [(20, [(G + "/instance-family", "In", ["nosuch2"])]), (10, [(wl.L_ARCH, "In", ["arm64"])])]
+            p["spreads"] = [{"key": wl.L_CT, "max_skew": 1, "when": "ScheduleAnyway", "selector": sel}]
+            pods.append(p)
+        return Problem(types, pods + wl.mixed_pods(30, 67, zones, fams), [soft])
+    raise KeyError(name)
 
 
 def scenario(name):
     """Named parity scenarios shared by the emulation (CPU) and GPU test files."""
+    if name in FEATURE_SCENARIOS:
+        return feature_scenario(name)
     zones, types = catalog776()
     if name == "c3_small":
         return Problem(types, wl.spread_pods(6, 20, 7), [wl.default_nodepool()])

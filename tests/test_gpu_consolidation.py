@@ -29,3 +29,8 @@ def test_candidates_order(L):
 def test_validate_command(L):
     from tests.cons_common import check_validate
     check_validate(L)
+
+
+def test_multi_node_more_than_100_candidates(L):
+    from tests.cons_common import check_multi_over_100
+    check_multi_over_100(L)

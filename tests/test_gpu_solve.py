@@ -4,7 +4,7 @@ requests, visit counters)."""
 import pytest
 
 from karpenter_amd import lib, workloads as wl
-from tests.helpers import Problem, catalog776, diff_results, families, scenario
+from tests.helpers import FEATURE_SCENARIOS, Problem, catalog776, diff_results, families, scenario
 
 pytestmark = pytest.mark.gpu
 
@@ -83,6 +83,23 @@ def test_scenarios_prefilter_path(L, name):
         L.set_collect_stats(True)
     d = diff_results(ro.decode(), rg.decode())
     assert d == "", d
+
+
+@pytest.mark.parametrize("name", FEATURE_SCENARIOS)
+def test_feature_scenarios(L, name):
+    """Every Preferences.Relax step, minDomains, daemon overhead / requests, node taints and tolerations, capacity-type
+    spread, required pod affinity, OR-ed node-affinity terms, negative operators (tests/helpers.feature_scenario): exact scan
+    with the visit counters compared, then the production setting (prefilter; the single-wave kernel where it applies)."""
+    prob = scenario(name)
+    ro, _ = check(L, prob)
+    L.set_collect_stats(False)
+    try:
+        rg = prob.run_library(L)
+    finally:
+        L.set_collect_stats(True)
+    d = diff_results(ro.decode(), rg.decode())
+    assert d == "", d
+    assert ro.res.relaxations == rg.res.relaxations
 
 
 def test_more_claims_than_the_lds_scan_order(L):
@@ -179,6 +196,13 @@ def test_wave_kernel_unschedulable_and_relaxation(LW):
     tainted = wl.default_nodepool("tainted", weight=10)
     tainted["taints"] = [("dedicated", "x", "NoSchedule")]
     _check_wave(LW, Problem(types, pods, [tainted, wl.default_nodepool()]))
+
+
+@pytest.mark.parametrize("name", ["prefer_no_schedule", "two_required_terms", "negative_selectors"])
+def test_wave_kernel_feature_scenarios(LW, name):
+    """The feature scenarios without topology groups / existing nodes run on the single-wave kernel: PreferNoSchedule
+    toleration relax, OR-ed required terms, NotIn / DoesNotExist / Exists / Gt / Lt."""
+    _check_wave(LW, scenario(name))
 
 
 def test_wave_kernel_scan_order_beyond_lds(LW):

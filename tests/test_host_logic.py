@@ -90,6 +90,27 @@ def test_scenarios_prefilter_path(L, name):
     assert d == "", d
 
 
+@pytest.mark.parametrize("name", __import__("tests.helpers", fromlist=["x"]).FEATURE_SCENARIOS)
+def test_feature_scenarios(L, name):
+    """Scheduler features beyond the BASELINE shapes: every Preferences.Relax step (OR-ed required terms, preferred pod
+    (anti-)affinity, preferred node affinity, ScheduleAnyway spreads, PreferNoSchedule toleration), minDomains, daemon
+    overhead / daemon requests, tainted nodes with Equal / Exists tolerations, capacity-type spread, required pod affinity,
+    NotIn / DoesNotExist / Exists / Gt / Lt selectors -- exact scan (visit counters equal the oracle's) and prefilter path."""
+    from tests.helpers import scenario
+    prob = scenario(name)
+    ro, _ = check(L, prob)
+    L.set_collect_stats(False)
+    try:
+        rg = prob.run_library(L)
+    finally:
+        L.set_collect_stats(True)
+    d = diff_results(ro.decode(), rg.decode())
+    assert d == "", d
+    assert ro.res.relaxations == rg.res.relaxations
+    if name in ("schedule_anyway", "prefer_no_schedule", "preferred_pod_affinity", "two_required_terms", "relax_everything"):
+        assert ro.res.relaxations > 0
+
+
 def test_more_claims_than_the_lds_scan_order(L):
     """> 2048 NodeClaims in flight: the scan order moves from LDS to global memory mid-solve; both counter settings."""
     from tests.helpers import scenario
