@@ -11,7 +11,7 @@ import os
 import pytest
 
 from karpenter_amd import lib, workloads as wl
-from tests.helpers import diff_results, full_size_problem, result_digest
+from tests.helpers import c4_full, diff_results, full_size_problem, records_digest, result_digest
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "fullsize_digests.json")
@@ -115,3 +115,36 @@ def test_c5_full(L):
     check_properties(prob, d)
     # weighted NodePools with limits: the limited pools never hold more CPU than their limit allows in the worst case
     assert result_digest(run(L, prob, False).decode()) == golden["digest"]
+
+
+def test_c4_full(L):
+    """BASELINE.json config 4 at its stated size: the 5 000-node cluster, every single-node candidate and the multi-node
+    prefixes 2..101, records against the oracle's committed digests (the oracle needs ~5 min for them) and the selected
+    commands; sharded evaluation (3 shards gathered) gives the same records."""
+    import numpy as np
+    from karpenter_amd import abi
+    golden = json.load(open(GOLDEN))["c4_full"]
+    types, nodes, bound, order = c4_full()
+    assert (len(nodes), len(bound)) == (golden["n_nodes"], golden["n_bound_pods"])
+    cat, cl = abi.build_catalog(types), abi.build_cluster(nodes, bound)
+    pend, nps = abi.build_pods([]), abi.build_nodepools([wl.default_nodepool()], wl.WELL_KNOWN_LABELS)
+    hcat, hcl = L.catalog_upload(cat), L.cluster_upload(cl)
+    try:
+        for multi in (False, True):
+            key = "multi" if multi else "single"
+            recs, _ = L.consolidate_records([hcat], hcl, pend, nps, abi.build_candidates(order), multi)
+            assert len(recs) == golden[key + "_records"]
+            assert [int((recs["decision"] == k).sum()) for k in (0, 1, 2)] == golden[key + "_decisions"]
+            assert records_digest(recs) == golden[key + "_digest"]
+            parts = [L.consolidate_records([hcat], hcl, pend, nps, abi.build_candidates(order, shard=s, n_shards=3), multi)[0] for s in range(3)]
+            allrec = np.concatenate(parts)
+            assert records_digest(allrec[np.argsort(allrec["candidate"], kind="stable")]) == golden[key + "_digest"]
+            dec = L.consolidate_select(hcat, allrec, len(order), multi)
+            if multi:
+                for k, v in golden["multi_decision"].items():
+                    assert dec[k] == v, (k, dec[k], v)
+            else:
+                assert dec["first_candidate"] == golden["single_first_command"] and dec["decision"] != 0
+    finally:
+        L.dll.kg_cluster_free(hcl)
+        L.dll.kg_catalog_free(hcat)
