@@ -428,6 +428,18 @@ int32_t kg_candidates_order(kg_ctx* ctx, kg_catalog* catalog, kg_cluster* cluste
 int32_t kg_solve(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, kg_cluster* cluster /* may be NULL */,
                  const kg_pods_desc* pods, const kg_nodepools_desc* nodepools, kg_results* out);
 
+/* kg_solve for callers that cannot allocate device memory -- code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE (its Solve allocates freely on the Go heap).  Same inputs, outputs,
+ * kernels and results as kg_solve; the per-solve device tables (problem image, solve state, per-NodeClaim rows) are carved
+ * from a static 32 MiB device array inside the library (one copy per GPU, resolved at kg_init) instead of pooled hipMalloc
+ * buffers, and the call makes no hipMalloc / hipFree / event creation.  A batch whose tables need more than the array
+ * returns KG_ENOMEM with the size in kg_last_error (C2's 10 000 pods need about 20 MiB); a batch that names a resource or
+ * label key the context has never seen returns KG_EUNSUPPORTED (the resident catalog tables would have to be rebuilt: run
+ * kg_solve once).  Every call on one GPU uses the same array: calls that overlap on one GPU (two contexts, two threads)
+ * race -- serialise them. */
+int32_t kg_solve_noalloc(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, kg_cluster* cluster /* may be NULL */,
+                         const kg_pods_desc* pods, const kg_nodepools_desc* nodepools, kg_results* out);
+
 /* InstanceTypes.Truncate(reqs, max) / OrderByPrice for a launch (instance.go:101): orders the
  * given types by (cheapest compatible available offering price, name) and keeps max_types. */
 int32_t kg_truncate(kg_ctx* ctx, kg_catalog* catalog, const kg_pools* pools, kg_range requirements,

@@ -294,7 +294,7 @@ void build_ec2_catalog(kg_ctx* ctx, const kg_ec2_catalog_desc* d, kg_catalog* ca
 
 extern "C" int32_t kg_catalog_build_ec2(kg_ctx* ctx, const kg_ec2_catalog_desc* desc, uint64_t generation, kg_catalog** out) {
   if (!ctx || !desc || !out) return KG_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  kg::CtxLock lk(ctx);
   std::unique_ptr<kg_catalog> cat(new kg_catalog());
   try {
     cat->ctx = ctx;

@@ -18,6 +18,7 @@ struct kg_ctx {
   int block_threads = 256;  // workgroup size of k_solve (256, 512 or 1024): 256 measured best (one wave per SIMD)
   bool collect_stats = true;  // maintain the reference-visit counters (exact; costs an extra pass per placement)
   std::mutex mu;
+  int device = 0;  // the GPU this context lives on (made current by every entry point)
   // Device buffers of finished solves, kept for the next one (a Solve needs three; hipMalloc / hipFree per call cost more
   // than the kernels of a small batch).  Used under `mu` only.
   std::vector<kg::DeviceBuffer> pool;
@@ -40,6 +41,23 @@ struct kg_ctx {
 };
 
 namespace kg {
+// context lock + the context's device made current for the calling thread
+struct CtxLock {
+  std::lock_guard<std::mutex> lk;
+  explicit CtxLock(kg_ctx* c) : lk(c->mu) { hal::use_device(c->device); }
+};
+// A fixed region of device memory that a solve carves its tables from instead of the context's pool (kg_solve_noalloc: the
+// library's static scratch array).  Nothing is ever allocated or freed; exceeding it is an error.
+struct FixedArena {
+  uint8_t* base = nullptr;
+  size_t cap = 0, used = 0;
+  void* take(size_t bytes, const char* what) {
+    const size_t off = (used + 255) & ~size_t(255);
+    if (off + bytes > cap) throw std::length_error(std::string("kg_solve_noalloc: the batch needs more than the ") + std::to_string(cap >> 20) + " MiB static device scratch (" + what + ")");
+    used = off + bytes;
+    return base + off;
+  }
+};
 HReq parse_req(Vocab& V, const kg_pools& p, const kg_requirement& q);
 HReqs parse_reqs(Vocab& V, const kg_pools& p, kg_range r);
 std::vector<std::pair<uint32_t, int64_t>> parse_rl(Vocab& V, const kg_pools& p, kg_range r);

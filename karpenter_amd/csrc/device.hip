@@ -1,8 +1,10 @@
 // device.hip -- gfx950 kernels and the HIP implementation of hal.hpp.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "hal.hpp"
 #include "solve_wave.hpp"
@@ -147,13 +149,28 @@ __global__ void __launch_bounds__(64) k_sim_gather(DevProblem P, SimBatch B, con
   if (i < (uint32_t)B.nsims) sim_gather(P, B, sims[i], i);
 }
 
+}  // namespace kg
+
+// Device memory of kg_solve_noalloc (include/karpgpu.h): the per-solve tables that kg_solve keeps in pooled hipMalloc
+// buffers (problem image, solve state, per-NodeClaim rows) live here instead, so the call allocates nothing.  Every GPU the
+// library runs on holds its own copy of the array until the process ends; the host only ever uses the per-device address
+// hipGetSymbolAddress returned at kg_init (`g_scratch_ptr`), never the symbol itself.
+constexpr size_t KG_SCRATCH_BYTES = 32u << 20;
+static __device__ __align__(256) unsigned char scratch[KG_SCRATCH_BYTES];
+
+namespace kg {
 namespace hal {
 
 static void ck(hipError_t e, const char* what) {
   if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
 
-std::string init(int device) {
+constexpr int KG_MAX_DEVICES = 64;
+static std::mutex g_dev_mu;
+static void* g_scratch_ptr[KG_MAX_DEVICES];             // per device: address of ITS copy of `scratch`
+static std::vector<hipEvent_t> g_events[KG_MAX_DEVICES];  // per device: timing events, created at init and reused
+
+std::string init(int device, int* device_out) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n == 0) return "no HIP device available (libkarpgpu has no CPU fallback)";
@@ -161,7 +178,34 @@ std::string init(int device) {
     e = hipSetDevice(device);
     if (e != hipSuccess) return std::string("hipSetDevice: ") + hipGetErrorString(e);
   }
+  int dev = 0;
+  e = hipGetDevice(&dev);
+  if (e != hipSuccess) return std::string("hipGetDevice: ") + hipGetErrorString(e);
+  if (dev < 0 || dev >= KG_MAX_DEVICES) return "device index out of range";
+  *device_out = dev;
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));  // (with `dev` current: each GPU has its own copy at its own address)
+    if (e != hipSuccess || !p) return std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
+    g_scratch_ptr[dev] = p;
+    for (int i = 0; i < 8; ++i) {
+      hipEvent_t ev;
+      e = hipEventCreate(&ev);
+      if (e != hipSuccess) return std::string("hipEventCreate: ") + hipGetErrorString(e);
+      g_events[dev].push_back(ev);
+    }
+  }
   return "";
+}
+void use_device(int device) { (void)hipSetDevice(device); }
+void* scratch_ptr(size_t* bytes) {
+  int dev = 0;
+  ck(hipGetDevice(&dev), "hipGetDevice");
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  if (dev < 0 || dev >= KG_MAX_DEVICES || !g_scratch_ptr[dev]) throw std::runtime_error("scratch array not set up on this device (kg_init)");
+  *bytes = KG_SCRATCH_BYTES;
+  return g_scratch_ptr[dev];
 }
 void* dmalloc(size_t bytes) {
   void* p = nullptr;
@@ -173,15 +217,31 @@ void h2d(void* dst, const void* src, size_t bytes) { if (bytes) ck(hipMemcpy(dst
 void d2h(void* dst, const void* src, size_t bytes) { if (bytes) ck(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost), "hipMemcpy D2H"); }
 void dzero(void* dst, size_t bytes) { if (bytes) ck(hipMemset(dst, 0, bytes), "hipMemset"); }
 
+// HIP-event bracket of one launch group; the events come from the device's pool (created at kg_init) and go back to it
 struct Timer {
   hipEvent_t a, b;
-  Timer() { ck(hipEventCreate(&a), "event"); ck(hipEventCreate(&b), "event"); ck(hipEventRecord(a, 0), "record"); }
+  int dev = 0;
+  static hipEvent_t take(int dev) {
+    {
+      std::lock_guard<std::mutex> lk(g_dev_mu);
+      if (!g_events[dev].empty()) { hipEvent_t e = g_events[dev].back(); g_events[dev].pop_back(); return e; }
+    }
+    hipEvent_t e;  // (more launches in flight than pooled events: concurrent callers)
+    ck(hipEventCreate(&e), "event");
+    return e;
+  }
+  Timer() {
+    ck(hipGetDevice(&dev), "hipGetDevice");
+    a = take(dev); b = take(dev);
+    ck(hipEventRecord(a, 0), "record");
+  }
   float stop() {
     ck(hipEventRecord(b, 0), "record");
     ck(hipEventSynchronize(b), "kernel execution");
     float ms = 0;
     ck(hipEventElapsedTime(&ms, a, b), "elapsed");
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    g_events[dev].push_back(a); g_events[dev].push_back(b);
     return ms;
   }
 };

@@ -8,7 +8,13 @@
 #include "hal.hpp"
 
 namespace kg::hal {
-std::string init(int) { return ""; }
+std::string init(int, int* device_out) { *device_out = 0; return ""; }
+void use_device(int) {}
+void* scratch_ptr(size_t* bytes) {
+  static void* p = std::calloc(32u << 20, 1);  // (stands in for the device array of device.hip)
+  *bytes = 32u << 20;
+  return p;
+}
 void* dmalloc(size_t bytes) { return std::calloc(bytes ? bytes : 8, 1); }
 void dfree(void* p) { std::free(p); }
 void h2d(void* dst, const void* src, size_t bytes) { if (bytes) std::memcpy(dst, src, bytes); }

@@ -7,8 +7,14 @@
 #include "solve_core.hpp"
 
 namespace kg::hal {
-// returns empty string on success, else the error text
-std::string init(int device);
+// returns empty string on success, else the error text.  device < 0 = the current device; *device_out = the device the
+// context lives on.  Set-up per device (once): the address of this device's copy of the library's static scratch array
+// (kg_solve_noalloc) and a few timing events, so that the no-allocation entry point never creates anything.
+std::string init(int device, int* device_out);
+// makes `device` current for the calling thread (every entry point, before it touches the GPU)
+void use_device(int device);
+// the current device's copy of the static scratch array and its size (device.hip: `scratch`)
+void* scratch_ptr(size_t* bytes);
 void* dmalloc(size_t bytes);
 void dfree(void* p);
 void h2d(void* dst, const void* src, size_t bytes);

@@ -293,8 +293,10 @@ struct Compiled {
   size_t o_nports, o_cports, o_crow = 0;  // o_crow: behind the state image (device-only, never uploaded)
   size_t o_nreq, o_creq, o_chead, o_chstamp, o_cmask, o_cbits, o_cmeta, o_cnpods, o_ctmpl, o_order, o_remaining, o_gcount, o_gdom, o_gpos, o_hcount, o_hpos, o_queue,
       o_podkind, o_excl, o_podindex, o_podreason, o_scratch, o_ordg, o_header, o_counters, o_nqueue;
+  bool fixed = false;  // the device buffers are carved from a FixedArena (kg_solve_noalloc): nothing to give back
   ~Compiled() {
     // (back to the context's pool; every path that builds or drops a Compiled holds ctx->mu)
+    if (fixed) return;
     ctx->pool_give(prob_dev.ptr, prob_cap);
     ctx->pool_give(state_dev.ptr, state_cap);
     ctx->pool_give(sims_dev.ptr, sims_cap);
@@ -354,6 +356,7 @@ struct SolveInputs {
   const kg_nodepools_desc* nps;
   ParsedPods* pending;
   int sim_cmax = 0;  // > 0: compile for a batch of simulations over subsets of `pending` with at most this many pods each
+  FixedArena* fixed = nullptr;  // device tables from this region instead of the context's pool; no allocation of any kind
   const std::vector<int32_t>* universe_bound = nullptr;  // simulations: bound-pod index of every pod of `pending`, -1 = a pending pod
   uint32_t n_shared = 0;                                  // simulations: pods [0, n_shared) take part in every simulation
 };
@@ -726,7 +729,11 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   const int R = (int)C.act_res.size();
   if (R > KG_MAXR) throw Unsupported("more than 8 distinct resources requested / limited in one solve");
   C.R = R;
-  if (in.cat->tab.R != (uint32_t)RG || in.cat->tab.key_row_off.size() != V.keys.size() || !in.cat->tab.dev.ptr) build_catalog_tables(ctx, in.cat);
+  if (in.cat->tab.R != (uint32_t)RG || in.cat->tab.key_row_off.size() != V.keys.size() || !in.cat->tab.dev.ptr) {
+    // (the batch names a resource or label key the context had not seen when the catalog tables were built)
+    if (in.fixed) throw Unsupported("kg_solve_noalloc: the resident catalog tables must be rebuilt for a resource / label key first seen in this batch (needs an allocation): run kg_solve once");
+    build_catalog_tables(ctx, in.cat);
+  }
   const CatalogTables& CT = in.cat->tab;
   const int T = (int)CT.T, TW = (int)CT.TW;
   C.T = T; C.TW = TW;
@@ -1166,7 +1173,9 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
                o_pctx = A.reserve_tail(sim_mode ? 8 : (size_t)std::max(NV, 1) * sizeof(PodCtx)), o_atab = A.reserve_tail(5 * KG_MAXR * 4),
                o_nlab = A.reserve_tail((size_t)std::max(S, 1) * NW * 8);
   C.prob_dev.bytes = A.total();
-  C.prob_dev.ptr = ctx->pool_take(C.prob_dev.bytes, &C.prob_cap);
+  C.fixed = in.fixed != nullptr;
+  if (in.fixed) { C.prob_dev.ptr = in.fixed->take(C.prob_dev.bytes, "problem tables"); C.prob_cap = C.prob_dev.bytes; }
+  else C.prob_dev.ptr = ctx->pool_take(C.prob_dev.bytes, &C.prob_cap);
   hal::h2d(C.prob_dev.ptr, A.bytes.data(), A.bytes.size());
   hal::dzero((uint8_t*)C.prob_dev.ptr + A.bytes.size(), C.prob_dev.bytes - A.bytes.size());
   auto dptr = [&](size_t off) { return (uint8_t*)C.prob_dev.ptr + off; };
@@ -1269,13 +1278,15 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   C.o_crow = C.state_bytes;
   if (sim_mode) return Cp;  // the caller lays out one slot per simulation
   C.state_dev.bytes = C.state_bytes + (C.wave_ok ? (size_t)Cmax * 896 : 8);  // claim rows of the single-wave solve (KG_ROW_WORDS * 8)
-  C.state_dev.ptr = ctx->pool_take(C.state_dev.bytes, &C.state_cap);
+  if (in.fixed) { C.state_dev.ptr = in.fixed->take(C.state_dev.bytes, "solve state"); C.state_cap = C.state_dev.bytes; }
+  else C.state_dev.ptr = ctx->pool_take(C.state_dev.bytes, &C.state_cap);
   hal::h2d(C.state_dev.ptr, C.state_image.data(), C.state_init_bytes);
   hal::dzero((uint8_t*)C.state_dev.ptr + C.state_init_bytes, C.state_bytes - C.state_init_bytes);
   C.sim = sim_at(C, (uint8_t*)C.state_dev.ptr);
   SimState& St = C.sim;
   C.sims_dev.bytes = sizeof(SimState);
-  C.sims_dev.ptr = ctx->pool_take(sizeof(SimState), &C.sims_cap);
+  if (in.fixed) { C.sims_dev.ptr = in.fixed->take(sizeof(SimState), "state descriptor"); C.sims_cap = sizeof(SimState); }
+  else C.sims_dev.ptr = ctx->pool_take(sizeof(SimState), &C.sims_cap);
   hal::h2d(C.sims_dev.ptr, &St, sizeof(SimState));
   KG_PROF("end");
   return Cp;
@@ -1358,13 +1369,14 @@ static int32_t fail(kg_ctx* ctx, int32_t code, const std::string& msg) {
 }
 
 static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* cluster, const kg_pods_desc* pods,
-                          const kg_nodepools_desc* nodepools, kg_results* out, bool add_pods_one);
+                          const kg_nodepools_desc* nodepools, kg_results* out, bool add_pods_one, FixedArena* fixed = nullptr);
 
 #define KG_GUARD_BEGIN try {
 #define KG_GUARD_END(ctx)                                                                   \
   } catch (const kg::Unsupported& e) { return fail(ctx, KG_EUNSUPPORTED, e.what()); }        \
   catch (const kgdesc::DescError& e) { return fail(ctx, KG_EINVAL, e.what()); }              \
   catch (const std::bad_alloc&) { return fail(ctx, KG_ENOMEM, "out of host memory"); }       \
+  catch (const std::length_error& e) { return fail(ctx, KG_ENOMEM, e.what()); }              \
   catch (const std::exception& e) { return fail(ctx, KG_EDEVICE, e.what()); }
 
 extern "C" {
@@ -1372,9 +1384,11 @@ extern "C" {
 int32_t kg_init(int32_t device, kg_ctx** out) {
   if (!out) return KG_EINVAL;
   *out = nullptr;
-  std::string err = hal::init(device);
+  int dev = 0;
+  std::string err = hal::init(device, &dev);
   if (!err.empty()) { fprintf(stderr, "kg_init: %s\n", err.c_str()); return KG_EDEVICE; }
   auto* ctx = new kg_ctx();
+  ctx->device = dev;
   Vocab& V = ctx->V;
   ctx->kHostname = V.key("kubernetes.io/hostname");
   ctx->kZone = V.key("topology.kubernetes.io/zone");
@@ -1390,13 +1404,14 @@ int32_t kg_init(int32_t device, kg_ctx** out) {
 }
 
 int32_t kg_destroy(kg_ctx* ctx) {
+  if (ctx) hal::use_device(ctx->device);  // (the pooled device buffers are freed on the context's GPU)
   delete ctx;
   return KG_OK;
 }
 
 int32_t kg_last_error(kg_ctx* ctx, char* buf, size_t n) {
   if (!ctx || !buf || n == 0) return KG_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  CtxLock lk(ctx);
   size_t m = std::min(n - 1, ctx->last_error.size());
   std::memcpy(buf, ctx->last_error.data(), m);
   buf[m] = 0;
@@ -1405,7 +1420,7 @@ int32_t kg_last_error(kg_ctx* ctx, char* buf, size_t n) {
 
 int32_t kg_stats_get(kg_ctx* ctx, kg_stats* out) {
   if (!ctx || !out) return KG_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  CtxLock lk(ctx);
   *out = ctx->stats;
   return KG_OK;
 }
@@ -1414,7 +1429,7 @@ const char* kg_backend(void) { return hal::backend(); }
 
 int32_t kg_set_collect_stats(kg_ctx* ctx, int32_t enabled) {
   if (!ctx) return KG_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  CtxLock lk(ctx);
   ctx->collect_stats = (enabled & 1) != 0;
   ctx->collect_timers = (enabled & 2) != 0;
   ctx->no_fast_path = (enabled & 16) != 0;
@@ -1437,7 +1452,7 @@ int32_t kg_abi_sizes(uint32_t* out, uint32_t cap) {
 
 int32_t kg_catalog_upload(kg_ctx* ctx, const kg_catalog_desc* desc, uint64_t generation, kg_catalog** out) {
   if (!ctx || !desc || !out) return KG_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  CtxLock lk(ctx);
   std::unique_ptr<kg_catalog> cat(new kg_catalog());
   KG_GUARD_BEGIN
   cat->ctx = ctx;
@@ -1459,7 +1474,7 @@ int32_t kg_catalog_size(kg_catalog* cat, uint32_t* n_types, uint64_t* generation
 int32_t kg_catalog_query(kg_catalog* cat, uint32_t type_index, const char* const* resource_names, uint32_t n, int64_t* capacity_milli,
                          int64_t* allocatable_milli, char* name_buf, size_t name_cap) {
   if (!cat || type_index >= cat->types.size()) return KG_EINVAL;
-  std::lock_guard<std::mutex> lk(cat->ctx->mu);
+  CtxLock lk(cat->ctx);
   const CatType& t = cat->types[type_index];
   for (uint32_t i = 0; i < n; ++i) {
     int rid = cat->ctx->V.resources.find(resource_names[i]);
@@ -1481,7 +1496,7 @@ int32_t kg_catalog_query(kg_catalog* cat, uint32_t type_index, const char* const
 int32_t kg_catalog_update_offerings(kg_ctx* ctx, kg_catalog* cat, const kg_strtab* strings, const kg_offering_update* updates, uint32_t n_updates,
                                     uint64_t generation) {
   if (!ctx || !cat || cat->ctx != ctx || !strings || (!updates && n_updates)) return KG_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  CtxLock lk(ctx);
   KG_GUARD_BEGIN
   update_offerings(ctx, cat, *strings, updates, n_updates);
   cat->generation = generation;
@@ -1492,7 +1507,7 @@ int32_t kg_catalog_update_offerings(kg_ctx* ctx, kg_catalog* cat, const kg_strta
 int32_t kg_catalog_free(kg_catalog* cat) {
   if (!cat) return KG_OK;
   {
-    std::lock_guard<std::mutex> lk(cat->ctx->mu);
+    CtxLock lk(cat->ctx);
     hal::dfree(cat->tab.dev.ptr);
   }
   delete cat;
@@ -1501,7 +1516,7 @@ int32_t kg_catalog_free(kg_catalog* cat) {
 
 int32_t kg_cluster_upload(kg_ctx* ctx, const kg_cluster_desc* desc, kg_cluster** out) {
   if (!ctx || !desc || !out) return KG_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  CtxLock lk(ctx);
   std::unique_ptr<kg_cluster> cl(new kg_cluster());
   KG_GUARD_BEGIN
   cl->ctx = ctx;
@@ -1542,7 +1557,7 @@ int32_t kg_cluster_free(kg_cluster* cl) {
 int32_t kg_candidates_order(kg_ctx* ctx, kg_catalog* catalog, kg_cluster* cluster, const kg_candidate_inputs* in, int32_t* out_nodes,
                             double* out_costs, uint32_t cap, uint32_t* n_out) {
   if (!ctx || !cluster || !n_out || (!out_nodes && cap)) return KG_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  CtxLock lk(ctx);
   KG_GUARD_BEGIN
   const size_t N = cluster->nodes.size();
   if (in && (in->lifetime_remaining || in->blocked)) check(in->n_nodes == N, "candidate inputs: node count");
@@ -1581,10 +1596,24 @@ int32_t kg_candidates_order(kg_ctx* ctx, kg_catalog* catalog, kg_cluster* cluste
 int32_t kg_solve(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, kg_cluster* cluster, const kg_pods_desc* pods,
                  const kg_nodepools_desc* nodepools, kg_results* out) {
   if (!ctx || !catalogs || n_catalogs == 0 || !pods || !nodepools || !out) return KG_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  CtxLock lk(ctx);
   KG_GUARD_BEGIN
   if (n_catalogs != 1) throw Unsupported("one catalog per solve on the device path");
   return solve_impl(ctx, catalogs, cluster, pods, nodepools, out, true);
+  KG_GUARD_END(ctx)
+}
+
+// kg_solve without any allocation of device memory: the per-solve tables go into the library's static scratch array
+// (device.hip: `scratch`, set up per device at kg_init) instead of pooled hipMalloc buffers.  Same kernels, same results.
+int32_t kg_solve_noalloc(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, kg_cluster* cluster, const kg_pods_desc* pods,
+                         const kg_nodepools_desc* nodepools, kg_results* out) {
+  if (!ctx || !catalogs || n_catalogs == 0 || !pods || !nodepools || !out) return KG_EINVAL;
+  CtxLock lk(ctx);
+  KG_GUARD_BEGIN
+  if (n_catalogs != 1) throw Unsupported("one catalog per solve on the device path");
+  FixedArena fa;
+  fa.base = (uint8_t*)hal::scratch_ptr(&fa.cap);
+  return solve_impl(ctx, catalogs, cluster, pods, nodepools, out, true, &fa);
   KG_GUARD_END(ctx)
 }
 
@@ -1592,13 +1621,14 @@ int32_t kg_solve(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, 
 
 // Scheduler.Solve on the device + result decode; the caller holds the context lock and the exception guard.
 static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* cluster, const kg_pods_desc* pods,
-                          const kg_nodepools_desc* nodepools, kg_results* out, bool add_pods_one) {
+                          const kg_nodepools_desc* nodepools, kg_results* out, bool add_pods_one, FixedArena* fixed) {
   {
   auto t0 = std::chrono::steady_clock::now();
   ParsedPods pending;
   parse_pods(ctx, pods, &pending, add_pods_one);
   check(out->cap_pods >= pending.pods.size(), "pod result capacity");
   SolveInputs in{ctx, catalogs[0], cluster, nodepools, &pending};
+  in.fixed = fixed;
   const bool stats = ctx->collect_stats;
   auto C = compile_problem(in, stats);
   auto t1 = std::chrono::steady_clock::now();
@@ -1870,7 +1900,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
                                 const kg_nodepools_desc* nodepools, const kg_candidates_desc* cands, bool multi, kg_candidate_record* records,
                                 uint32_t cap_records, uint32_t* n_records, double* device_ms, ValidateOut* vout = nullptr) {
   if (!ctx || !catalogs || n_catalogs == 0 || !cluster || !nodepools || !cands || !n_records || (!records && cap_records)) return KG_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  CtxLock lk(ctx);
   KG_GUARD_BEGIN
   if (n_catalogs != 1) throw Unsupported("one catalog per solve on the device path");
   kg_catalog* cat = catalogs[0];
@@ -2260,7 +2290,7 @@ int32_t kg_consolidate_validate(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
 int32_t kg_consolidate_select(kg_ctx* ctx, kg_catalog* catalog, int32_t multi, const kg_candidate_record* records, uint32_t n_records,
                               uint32_t n_candidates, kg_decision* out) {
   if (!ctx || !catalog || !out || (!records && n_records)) return KG_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  CtxLock lk(ctx);
   KG_GUARD_BEGIN
   const kg_candidate_record* win = nullptr;
   int win_n = 0;
@@ -2332,7 +2362,7 @@ extern "C" {
 int32_t kg_truncate(kg_ctx* ctx, kg_catalog* catalog, const kg_pools* pools, kg_range requirements, const uint32_t* type_ids, uint32_t n_types,
                     int32_t max_types, uint32_t* out_type_ids, uint32_t* n_out, uint8_t* min_values_failed) {
   if (!ctx || !catalog || !pools || (!type_ids && n_types) || !out_type_ids || !n_out) return KG_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  CtxLock lk(ctx);
   KG_GUARD_BEGIN
   HReqs reqs = parse_reqs(ctx->V, *pools, requirements);
   ClaimView cv;
@@ -2349,7 +2379,7 @@ int32_t kg_truncate(kg_ctx* ctx, kg_catalog* catalog, const kg_pools* pools, kg_
 int32_t kg_launch_filter(kg_ctx* ctx, kg_catalog* catalog, const kg_pools* pools, kg_range requirements, kg_range requests, int32_t max_types,
                          uint32_t* out_type_ids, uint32_t cap, uint32_t* n_out, uint8_t* min_values_failed) {
   if (!ctx || !catalog || !pools || !n_out || (!out_type_ids && cap)) return KG_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  CtxLock lk(ctx);
   KG_GUARD_BEGIN
   check(pools->strings.count > 0, "launch filter needs a non-empty string table");
   Vocab& V = ctx->V;

@@ -14,7 +14,7 @@ DEFAULT_PATH = os.path.join(_HERE, "libkarpgpu.so")
 
 EXPORTS = ["kg_init", "kg_destroy", "kg_last_error", "kg_stats_get", "kg_catalog_upload", "kg_catalog_build_ec2", "kg_catalog_update_offerings", "kg_candidates_order", "kg_consolidate_validate",
            "kg_catalog_query", "kg_catalog_size", "kg_catalog_free", "kg_cluster_upload", "kg_cluster_free", "kg_solve",
-           "kg_truncate", "kg_launch_filter", "kg_consolidate_single", "kg_consolidate_multi", "kg_consolidate_select"]
+           "kg_truncate", "kg_launch_filter", "kg_consolidate_single", "kg_consolidate_multi", "kg_consolidate_select", "kg_solve_noalloc"]
 
 
 class KgError(RuntimeError):
@@ -42,6 +42,7 @@ class Library:
         d.kg_cluster_upload.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         d.kg_cluster_free.argtypes = [C.c_void_p]
         d.kg_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        d.kg_solve_noalloc.argtypes = d.kg_solve.argtypes
         d.kg_backend.restype = C.c_char_p
         for fn in (d.kg_consolidate_single, d.kg_consolidate_multi):
             fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
@@ -139,10 +140,12 @@ class Library:
         self._check(self.dll.kg_cluster_upload(self.ctx, C.addressof(built.desc), C.byref(h)))
         return h
 
-    def solve(self, catalogs, cluster, pods, nodepools, n_pods, cap_claims=None):
+    def solve(self, catalogs, cluster, pods, nodepools, n_pods, cap_claims=None, noalloc=False):
+        """kg_solve; noalloc=True -> kg_solve_noalloc (device tables in the library's static scratch array)."""
         arr = (C.c_void_p * len(catalogs))(*catalogs)
         rb = abi.ResultBuffers(n_pods, cap_claims)
-        self._check(self.dll.kg_solve(self.ctx, arr, len(catalogs), cluster, C.addressof(pods.desc), C.addressof(nodepools.desc),
+        fn = self.dll.kg_solve_noalloc if noalloc else self.dll.kg_solve
+        self._check(fn(self.ctx, arr, len(catalogs), cluster, C.addressof(pods.desc), C.addressof(nodepools.desc),
                                       C.addressof(rb.res)))
         return rb
 
