@@ -389,6 +389,11 @@ int32_t kg_catalog_build_ec2(kg_ctx* ctx, const kg_ec2_catalog_desc* desc, uint6
 int32_t kg_catalog_query(kg_catalog* cat, uint32_t type_index, const char* const* resource_names, uint32_t n,
                          int64_t* capacity_milli, int64_t* allocatable_milli, char* name_buf, size_t name_cap);
 int32_t kg_catalog_size(kg_catalog* cat, uint32_t* n_types, uint64_t* generation);
+/* read back the scheduling requirements the encoder holds for type i (computeRequirements, types.go:74-172, as maintained by
+ * kg_catalog_update_offerings): one line per label key in lexicographic key order, "key<TAB>In<TAB>v1,v2,...\n" with the
+ * values sorted, or "key<TAB>DoesNotExist<TAB>\n".  *needed = bytes required including the terminating 0; KG_ENOMEM when
+ * cap is smaller (buf then holds a truncated, terminated prefix). */
+int32_t kg_catalog_query_requirements(kg_catalog* cat, uint32_t type_index, char* buf, size_t cap, size_t* needed);
 /* In-place maintenance of a resident catalog: replaces re-running DefaultProvider.List after an
  * ICE mark (pkg/cache/unavailableofferings.go:55-65 bumps SeqNum, which is part of the cache key of
  * instancetype.go:127-136) or a spot price refresh (pkg/providers/pricing/pricing.go:357-400).  Every update names an

@@ -108,18 +108,35 @@ void build_catalog_tables(kg_ctx* ctx, kg_catalog* cat) {
       for (uint32_t t = 0; t < T; ++t) if (cv[t] <= x) cthr_mask[base + (t >> 6)] |= 1ull << (t & 63);
     }
   }
-  // per key value->types masks
+  // per key value->types masks, rows in the catalog's own value numbering
   const uint32_t K = (uint32_t)V.keys.size();
   C.key_row_off.assign(K, UINT32_MAX);
   C.key_nvals.assign(K, 0);
   C.kU.assign(K, std::vector<uint64_t>(tw, 0));
   C.kN.assign(K, C.all_types);
+  C.cvals.assign(K, {});
+  C.cmap.assign(K, {});
   std::vector<uint64_t> twv;
   std::vector<uint8_t> mentioned(K, 0);
-  for (auto& t : cat->types) for (auto& r : t.reqs.rs) mentioned[r.key] = 1;
+  for (auto& t : cat->types) {
+    for (auto& r : t.reqs.rs) { mentioned[r.key] = 1; C.cvals[r.key].insert(C.cvals[r.key].end(), r.vals.begin(), r.vals.end()); }
+    for (auto& o : t.offerings) {
+      // (offerings that are not available keep their values numbered: kg_catalog_update_offerings may bring them back)
+      mentioned[ctx->kZone] = mentioned[ctx->kCT] = 1;
+      C.cvals[ctx->kZone].push_back(o.zone); C.cvals[ctx->kCT].push_back(o.ct);
+      if (o.zid >= 0) { mentioned[ctx->kZid] = 1; C.cvals[ctx->kZid].push_back((uint32_t)o.zid); }
+    }
+  }
+  for (uint32_t k = 0; k < K; ++k) {
+    auto& cv = C.cvals[k];
+    std::sort(cv.begin(), cv.end());
+    cv.erase(std::unique(cv.begin(), cv.end()), cv.end());
+    std::sort(cv.begin(), cv.end(), [&](uint32_t a, uint32_t b) { return V.vals[k].strs[a] < V.vals[k].strs[b]; });
+    for (uint32_t l = 0; l < cv.size(); ++l) C.cmap[k].emplace(cv[l], l);
+  }
   for (uint32_t k = 0; k < K; ++k) {
     if (!mentioned[k]) continue;
-    const uint32_t nv = (uint32_t)V.vals[k].size();
+    const uint32_t nv = (uint32_t)C.cvals[k].size();
     C.key_row_off[k] = (uint32_t)(twv.size() / tw);
     C.key_nvals[k] = nv;
     size_t base = twv.size();
@@ -129,13 +146,15 @@ void build_catalog_tables(kg_ctx* ctx, kg_catalog* cat) {
       if (!r) continue;
       C.kN[k][t >> 6] &= ~(1ull << (t & 63));
       if (r->vals.empty()) C.kU[k][t >> 6] |= 1ull << (t & 63);
-      for (uint32_t v : r->vals) twv[base + (size_t)v * tw + (t >> 6)] |= 1ull << (t & 63);
+      for (uint32_t v : r->vals) twv[base + (size_t)C.local(k, v) * tw + (t >> 6)] |= 1ull << (t & 63);
     }
   }
   // offerings
-  const uint32_t nz = (uint32_t)V.vals[ctx->kZone].size(), nct = (uint32_t)V.vals[ctx->kCT].size();
-  if (nz > 64 || nct > 4) throw Unsupported("more than 64 zones or 4 capacity types");
+  const uint32_t nz = (uint32_t)C.cvals[ctx->kZone].size(), nct = (uint32_t)C.cvals[ctx->kCT].size();
+  if (nz > 64 || nct > 4 || C.cvals[ctx->kZid].size() > 64) throw Unsupported("catalog with more than 64 zones, 64 zone ids or 4 capacity types");
   C.n_zone_vals = nz; C.n_ct_vals = nct;
+  for (auto& t : cat->types)
+    for (auto& o : t.offerings) { o.lz = (uint32_t)C.local(ctx->kZone, o.zone); o.lct = (uint32_t)C.local(ctx->kCT, o.ct); o.lzid = o.zid < 0 ? -1 : C.local(ctx->kZid, (uint32_t)o.zid); }
   std::vector<uint64_t> offmask((size_t)64 * 4 * tw, 0);
   std::vector<uint8_t> zone_zid(64, 0xFF);
   std::vector<uint32_t> off_begin(T + 1, 0);
@@ -145,14 +164,13 @@ void build_catalog_tables(kg_ctx* ctx, kg_catalog* cat) {
   for (uint32_t t = 0; t < T; ++t) {
     off_begin[t] = (uint32_t)off_zone.size();
     for (auto& o : cat->types[t].offerings) {
-      if (o.available) offmask[((size_t)o.zone * 4 + o.ct) * tw + (t >> 6)] |= 1ull << (t & 63);
-      if (o.zid >= 0) {
-        if (o.zid > 63) throw Unsupported("more than 64 zone ids");
-        if (zone_zid[o.zone] != 0xFF && zone_zid[o.zone] != (uint8_t)o.zid) throw Unsupported("zone with two zone ids");
-        zone_zid[o.zone] = (uint8_t)o.zid;
+      if (o.available) offmask[((size_t)o.lz * 4 + o.lct) * tw + (t >> 6)] |= 1ull << (t & 63);
+      if (o.lzid >= 0) {
+        if (zone_zid[o.lz] != 0xFF && zone_zid[o.lz] != (uint8_t)o.lzid) throw Unsupported("zone with two zone ids");
+        zone_zid[o.lz] = (uint8_t)o.lzid;
       }
-      off_zone.push_back((uint16_t)o.zone); off_ct.push_back((uint16_t)o.ct);
-      off_zid.push_back(o.zid < 0 ? 0xFFFF : (uint16_t)o.zid);
+      off_zone.push_back((uint16_t)o.lz); off_ct.push_back((uint16_t)o.lct);
+      off_zid.push_back(o.lzid < 0 ? 0xFFFF : (uint16_t)o.lzid);
       off_price.push_back(o.price); off_avail.push_back(o.available);
     }
   }
@@ -160,7 +178,7 @@ void build_catalog_tables(kg_ctx* ctx, kg_catalog* cat) {
   // an offering without zone id next to offerings of the same zone with one would break the zone->zid fold
   for (uint32_t t = 0; t < T; ++t)
     for (auto& o : cat->types[t].offerings)
-      if (o.zid < 0 && zone_zid[o.zone] != 0xFF) throw Unsupported("zone id present on some offerings of a zone only");
+      if (o.lzid < 0 && zone_zid[o.lz] != 0xFF) throw Unsupported("zone id present on some offerings of a zone only");
   std::vector<uint16_t> name_rank(std::max(T, 1u), 0);
   {
     std::vector<uint32_t> idx(T);
@@ -222,13 +240,10 @@ void update_offerings(kg_ctx* ctx, kg_catalog* cat, const kg_strtab& strings, co
     // offering availability per (zone, capacity type)
     std::set<std::pair<uint32_t, uint32_t>> avail;
     for (auto& o : ty.offerings) if (o.available) avail.insert({o.zone, o.ct});
-    for (auto& o : ty.offerings) set_bit(C.o_offmask + ((size_t)o.zone * 4 + o.ct) * tw * 8, t, avail.count({o.zone, o.ct}) != 0);
+    for (auto& o : ty.offerings) set_bit(C.o_offmask + ((size_t)o.lz * 4 + o.lct) * tw * 8, t, avail.count({o.zone, o.ct}) != 0);
     // computeRequirements: zone / capacity-type / zone-id In {values of the available offerings}
     for (int k3 = 0; k3 < 3; ++k3) {
       const uint32_t key = keys3[k3];
-      HReq* cur = nullptr;
-      for (auto& r : ty.reqs.rs) if (r.key == key) cur = &r;
-      if (!cur) continue;  // a type that never mentioned the key keeps not mentioning it
       std::vector<uint32_t> vals;
       for (auto& o : ty.offerings) {
         if (!o.available) continue;
@@ -238,13 +253,21 @@ void update_offerings(kg_ctx* ctx, kg_catalog* cat, const kg_strtab& strings, co
       }
       std::sort(vals.begin(), vals.end());
       vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
-      cur->vals = vals;
+      HReq* cur = nullptr;
+      for (auto& r : ty.reqs.rs) if (r.key == key) cur = &r;
+      // the zone-id requirement exists exactly while some available offering carries a zone id (types.go:110-117); zone
+      // and capacity type are always listed (types.go:80-88), with no value when nothing is available
+      const bool want = k3 != 2 ? cur != nullptr : !vals.empty();
+      if (want && !cur) { ty.reqs.add(V, hreq_new(V, key, KG_OP_IN, vals, -1)); for (auto& r : ty.reqs.rs) if (r.key == key) cur = &r; }
+      if (!want && cur) { ty.reqs.rs.erase(ty.reqs.rs.begin() + (cur - ty.reqs.rs.data())); cur = nullptr; }
+      if (cur) cur->vals = vals;
       if (key < C.key_row_off.size() && C.key_row_off[key] != UINT32_MAX) {
-        for (uint32_t v = 0; v < C.key_nvals[key]; ++v)
-          set_bit(C.o_twv + ((size_t)C.key_row_off[key] + v) * tw * 8, t, std::binary_search(vals.begin(), vals.end(), v));
-        // a requirement left without values reads as DoesNotExist
-        uint64_t& ku = C.kU[key][t >> 6];
-        if (vals.empty()) ku |= 1ull << (t & 63); else ku &= ~(1ull << (t & 63));
+        for (uint32_t l = 0; l < C.key_nvals[key]; ++l)
+          set_bit(C.o_twv + ((size_t)C.key_row_off[key] + l) * tw * 8, t, cur && std::binary_search(vals.begin(), vals.end(), C.cvals[key][l]));
+        // a requirement left without values reads as DoesNotExist; a type without the requirement does not mention the key
+        uint64_t &ku = C.kU[key][t >> 6], &kn = C.kN[key][t >> 6];
+        if (cur && vals.empty()) ku |= 1ull << (t & 63); else ku &= ~(1ull << (t & 63));
+        if (!cur) kn |= 1ull << (t & 63); else kn &= ~(1ull << (t & 63));
       }
     }
     // prices / availability columns of the offering table

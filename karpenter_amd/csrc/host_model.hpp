@@ -45,8 +45,11 @@ struct StrMap {
   size_t size() const { return strs.size(); }
 };
 
-// Context-wide vocabulary: ids never change once assigned, so device-resident catalog tables
-// stay valid while later solves add keys / values / resources.
+// Context-wide vocabulary: a host-side string interner (ids never change once assigned).  VALUE ids never reach the device:
+// a catalog numbers the values it mentions itself (CatalogTables::cvals, "catalog-local" ids) and every Solve numbers the
+// values its own batch uses (Compiled::lv, "solve-local" ids = the catalog's, then the batch's extras), so no device table,
+// row width or kernel choice depends on what a long-lived context has seen before.  Key and resource ids do index host
+// tables; they are as few as the label keys and resource names of the cluster.
 struct Vocab {
   StrMap keys;
   std::vector<StrMap> vals;                 // per key
@@ -189,8 +192,10 @@ struct Arena {
 
 // ---------------------------------------------------------------- catalog (host view + device tables)
 struct CatOffering {
-  uint32_t zone, ct;  // value ids of the zone / capacity-type keys
+  uint32_t zone, ct;  // (context) value ids of the zone / capacity-type keys
   int zid;            // value id of the zone-id key or -1
+  uint32_t lz = 0, lct = 0;  // catalog-local ids of the same values (CatalogTables::cvals): what masks and device tables index
+  int lzid = -1;
   double price;
   bool available;
 };
@@ -212,7 +217,16 @@ struct CatalogTables {  // offsets into `image`; rebuilt when the context's reso
   size_t o_thr_val, o_thr_off, o_thr_n, o_thr_mask, o_cthr_val, o_cthr_off, o_cthr_n, o_cthr_mask, o_valid, o_cap, o_alloc, o_twv, o_offmask,
       o_zone_zid, o_name_rank, o_off_begin, o_off_zone, o_off_ct, o_off_zid, o_off_price, o_off_avail;
   std::vector<uint32_t> key_row_off;  // per global key: first twv row, or UINT32_MAX
-  std::vector<uint32_t> key_nvals;    // per global key: rows (= values the catalog knew at build time)
+  std::vector<uint32_t> key_nvals;    // per global key: rows (= values the catalog's types / offerings carry on the key)
+  // catalog-local value numbering per global key: the values the catalog's types and offerings mention, in lexicographic
+  // order (a property of the catalog's content alone: the same in every process that uploads the same catalog)
+  std::vector<std::vector<uint32_t>> cvals;                       // catalog-local id -> context value id
+  std::vector<std::unordered_map<uint32_t, uint32_t>> cmap;      // context value id -> catalog-local id
+  int local(uint32_t key, uint32_t v) const {
+    if (key >= cmap.size()) return -1;
+    auto f = cmap[key].find(v);
+    return f == cmap[key].end() ? -1 : (int)f->second;
+  }
   std::vector<std::vector<uint64_t>> kU, kN;  // per global key [TW]; keys unknown to the catalog: kN = all
   std::vector<uint64_t> all_types;
   uint32_t n_zone_vals = 0, n_ct_vals = 0;

@@ -264,9 +264,38 @@ struct Interner {
 
 }  // namespace
 
+// Solve-local numbering of the values of one active label key: the catalog's own numbering first (so the catalog's resident
+// value->types rows, offering masks and zone -> zone-id table apply unchanged), then the values only this batch mentions
+// (pod / NodePool requirements, labels of the cluster's nodes) in order of appearance.  Requirement rows, topology domain
+// counters and node label ids on the device use these ids: their size is a property of the batch and the catalog, never
+// of what the context has seen before.
+struct LocalVocab {
+  const std::vector<uint32_t>* cat_vals = nullptr;                  // catalog-local id -> context value id
+  const std::unordered_map<uint32_t, uint32_t>* cat_map = nullptr;
+  std::vector<uint32_t> extra;
+  std::unordered_map<uint32_t, uint32_t> xmap;
+  uint32_t ncat() const { return cat_vals ? (uint32_t)cat_vals->size() : 0; }
+  uint32_t size() const { return ncat() + (uint32_t)extra.size(); }
+  uint32_t global(uint32_t l) const { return l < ncat() ? (*cat_vals)[l] : extra[l - ncat()]; }
+  int find(uint32_t g) const {
+    if (cat_map) { auto f = cat_map->find(g); if (f != cat_map->end()) return (int)f->second; }
+    auto f = xmap.find(g);
+    return f == xmap.end() ? -1 : (int)f->second;
+  }
+  uint32_t id(uint32_t g) {
+    const int l = find(g);
+    if (l >= 0) return (uint32_t)l;
+    const uint32_t n = size();
+    extra.push_back(g);
+    xmap.emplace(g, n);
+    return n;
+  }
+};
+
 struct Compiled {
   kg_ctx* ctx;
   kg_catalog* cat;
+  std::vector<LocalVocab> lv;        // per active slot
   std::vector<Template> templates;
   std::vector<uint32_t> node_order;  // scan position -> cluster node index
   std::vector<uint32_t> slot_key;    // active slot -> global key
@@ -603,18 +632,45 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   const int Ka = (int)C.slot_key.size();
   if (Ka > KG_MAXKA) throw Unsupported("more than 32 active label keys");
   C.Ka = Ka;
+  // ---- solve-local value numbering of every active key: the catalog's values, then what this batch adds (requirement
+  // sets, labels of the cluster's nodes -- deleting nodes too: their bound pods count in topology domains)
+  if (!in.cat->tab.dev.ptr || in.cat->tab.R != (uint32_t)V.resources.size()) {
+    if (in.fixed) throw Unsupported("kg_solve_noalloc: the resident catalog tables must be rebuilt for a resource first seen in this batch (needs an allocation): run kg_solve once");
+    build_catalog_tables(ctx, in.cat);
+  }
+  C.lv.resize(std::max(Ka, 1));
+  {
+    const CatalogTables& CT0 = in.cat->tab;
+    std::vector<int> slot_of(V.keys.size(), -1);
+    for (int a = 0; a < Ka; ++a) {
+      const uint32_t k = C.slot_key[a];
+      slot_of[k] = a;
+      if (k < CT0.cvals.size()) { C.lv[a].cat_vals = &CT0.cvals[k]; C.lv[a].cat_map = &CT0.cmap[k]; }
+    }
+    for (auto& r : reqsets) for (auto& q : r.rs) if (slot_of[q.key] >= 0) for (uint32_t v : q.vals) C.lv[slot_of[q.key]].id(v);
+    for (auto& tp : C.templates) for (auto& q : tp.spec_reqs.rs) if (slot_of[q.key] >= 0) for (uint32_t v : q.vals) C.lv[slot_of[q.key]].id(v);
+    if (in.cluster)
+      for (auto& nd : in.cluster->nodes) for (auto& kv : nd.labels) if (slot_of[kv.first] >= 0) C.lv[slot_of[kv.first]].id(kv.second);
+  }
+  auto lid = [&](int a, uint32_t g) -> uint32_t {  // solve-local id of a value the batch is known to mention
+    const int l = C.lv[a].find(g);
+    if (l < 0) throw std::logic_error("value outside the solve-local vocabulary");
+    return (uint32_t)l;
+  };
   C.aoff.resize(std::max(Ka, 1)); C.aw.resize(std::max(Ka, 1)); C.slot2spec.assign(std::max(Ka, 1), -1);
   int Wa = 0;
   uint32_t wk_slots = 0;
   for (int a = 0; a < Ka; ++a) {
     const uint32_t k = C.slot_key[a];
-    const int w = (int)((V.vals[k].size() + 63) / 64);
+    const uint32_t nlocal = C.lv[a].size();
+    if (nlocal >= 0xFFFF) throw Unsupported("more than 65534 values on one label key in one solve");
+    const int w = (int)((nlocal + 63) / 64);
     C.aoff[a] = (uint16_t)Wa;
     C.aw[a] = (uint16_t)std::max(w, 1);
     Wa += C.aw[a];
     if (well_known.count(k)) wk_slots |= 1u << a;
     if (is_multi[k] || is_topo[k]) {
-      if (V.vals[k].size() > 64) throw Unsupported("topology / multi-valued key with more than 64 values");
+      if (nlocal > 64) throw Unsupported("topology / multi-valued key with more than 64 values in this solve (catalog + batch)");
       if (C.spec_slot.size() >= KG_MAXSPEC) throw Unsupported("more than 6 special keys");
       C.slot2spec[a] = (int8_t)C.spec_slot.size();
       C.spec_slot.push_back((uint8_t)a);
@@ -648,15 +704,20 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     const int w = C.aw[a];
     gtmask.resize(gtmask.size() + (size_t)16 * w, 0);
     ltmask.resize(ltmask.size() + (size_t)16 * w, 0);
+    const uint32_t nl = C.lv[a].size();
     for (size_t i = 0; i < gts[a].size(); ++i) {
       gtval[a * 16 + i] = gts[a][i];
-      for (uint32_t v = 0; v < V.vals[k].size(); ++v)
-        if (V.isint[k][v] && V.ival[k][v] > gts[a][i]) gtmask[bndmask_off[a] + i * w + (v >> 6)] |= 1ull << (v & 63);
+      for (uint32_t l = 0; l < nl; ++l) {
+        const uint32_t v = C.lv[a].global(l);
+        if (V.isint[k][v] && V.ival[k][v] > gts[a][i]) gtmask[bndmask_off[a] + i * w + (l >> 6)] |= 1ull << (l & 63);
+      }
     }
     for (size_t i = 0; i < lts[a].size(); ++i) {
       ltval[a * 16 + i] = lts[a][i];
-      for (uint32_t v = 0; v < V.vals[k].size(); ++v)
-        if (V.isint[k][v] && V.ival[k][v] < lts[a][i]) ltmask[bndmask_off[a] + i * w + (v >> 6)] |= 1ull << (v & 63);
+      for (uint32_t l = 0; l < nl; ++l) {
+        const uint32_t v = C.lv[a].global(l);
+        if (V.isint[k][v] && V.ival[k][v] < lts[a][i]) ltmask[bndmask_off[a] + i * w + (l >> 6)] |= 1ull << (l & 63);
+      }
     }
   }
   auto gt_idx = [&](int a, int64_t x) { return (uint32_t)(std::lower_bound(gts[a].begin(), gts[a].end(), x) - gts[a].begin()) + 1; };
@@ -700,7 +761,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
       e_bits.push_back((uint32_t)rs_bits.size());
       size_t base = rs_bits.size();
       rs_bits.resize(base + C.aw[a], 0);
-      for (uint32_t v : q.vals) rs_bits[base + (v >> 6)] |= 1ull << (v & 63);
+      for (uint32_t v : q.vals) { const uint32_t l = lid(a, v); rs_bits[base + (l >> 6)] |= 1ull << (l & 63); }
       ne++;
     }
     if (ne > KG_MAXE) throw Unsupported("requirement set with more than 8 keys");
@@ -729,12 +790,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   const int R = (int)C.act_res.size();
   if (R > KG_MAXR) throw Unsupported("more than 8 distinct resources requested / limited in one solve");
   C.R = R;
-  if (in.cat->tab.R != (uint32_t)RG || in.cat->tab.key_row_off.size() != V.keys.size() || !in.cat->tab.dev.ptr) {
-    // (the batch names a resource or label key the context had not seen when the catalog tables were built)
-    if (in.fixed) throw Unsupported("kg_solve_noalloc: the resident catalog tables must be rebuilt for a resource / label key first seen in this batch (needs an allocation): run kg_solve once");
-    build_catalog_tables(ctx, in.cat);
-  }
-  const CatalogTables& CT = in.cat->tab;
+  const CatalogTables& CT = in.cat->tab;  // (rebuilt above when the batch named a resource the tables do not cover)
   const int T = (int)CT.T, TW = (int)CT.TW;
   C.T = T; C.TW = TW;
 
@@ -747,8 +803,9 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   auto poddom = [&](const HReqs& strict, uint32_t key) {
     const HReq* q = strict.find(key);
     if (!q) return (uint64_t)~0ull;
+    const int a = find_slot(C, key);
     uint64_t m = 0;
-    for (uint32_t v = 0; v < V.vals[key].size() && v < 64; ++v) if (q->has(V, v)) m |= 1ull << v;
+    for (uint32_t l = 0; a >= 0 && l < C.lv[a].size() && l < 64; ++l) if (q->has(V, C.lv[a].global(l))) m |= 1ull << l;
     return m;
   };
   std::vector<uint16_t> ghidx(G, 0xFFFF);
@@ -916,8 +973,9 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     for (auto& kv : nd.labels) {
       int a = find_slot(C, kv.first);
       if (a < 0) continue;
-      nval[(size_t)a * N + n] = (uint16_t)kv.second;
-      if (C.slot2spec[a] >= 0) ndom[(size_t)C.slot2spec[a] * N + n] = (uint16_t)kv.second;
+      const uint32_t l = lid(a, kv.second);
+      nval[(size_t)a * N + n] = (uint16_t)l;
+      if (C.slot2spec[a] >= 0) ndom[(size_t)C.slot2spec[a] * N + n] = (uint16_t)l;
     }
     if (valid)
       for (size_t ts = 0; ts < tolsets.size(); ++ts)
@@ -956,15 +1014,16 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     // universe per special key: union over templates x types of (template ∩ type) values, plus template In values
     std::vector<uint64_t> universe(std::max(nspec, 1), 0);
     for (int sp = 0; sp < nspec; ++sp) {
-      const uint32_t key = C.slot_key[C.spec_slot[sp]];
+      const int sa = C.spec_slot[sp];
+      const uint32_t key = C.slot_key[sa];
       for (auto& tp : C.templates) {
         const HReq* tq = tp.spec_reqs.find(key);
         for (auto& ty : in.cat->types) {
           const HReq* yq = ty.reqs.find(key);
-          if (yq && tq) { HReq m = hreq_intersect(V, *tq, *yq); for (uint32_t v : m.vals) universe[sp] |= 1ull << v; }
-          else if (yq) { for (uint32_t v : yq->vals) universe[sp] |= 1ull << v; }
+          if (yq && tq) { HReq m = hreq_intersect(V, *tq, *yq); for (uint32_t v : m.vals) universe[sp] |= 1ull << lid(sa, v); }
+          else if (yq) { for (uint32_t v : yq->vals) universe[sp] |= 1ull << lid(sa, v); }
         }
-        if (tq) for (uint32_t v : tq->vals) universe[sp] |= 1ull << v;  // (.values inserted whatever the operator)
+        if (tq) for (uint32_t v : tq->vals) universe[sp] |= 1ull << lid(sa, v);  // (.values inserted whatever the operator)
       }
     }
     for (int g = 0; g < G; ++g) {
@@ -1020,11 +1079,12 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
         }
         for (auto& kv : nd.labels) {
           if (kv.first != groups[g].key) continue;
-          if (kv.second > 63) throw Unsupported("topology domain id over 63");
-          gcount0[(size_t)g * 64 + kv.second]++;
-          gdom0[g] |= 1ull << kv.second;
-          gpos0[g] |= 1ull << kv.second;
-          if (u >= 0) C.contrib[u].push_back((uint32_t)(g * 64 + kv.second));
+          const uint32_t d = lid(find_slot(C, kv.first), kv.second);
+          if (d > 63) throw Unsupported("topology domain id over 63");
+          gcount0[(size_t)g * 64 + d]++;
+          gdom0[g] |= 1ull << d;
+          gpos0[g] |= 1ull << d;
+          if (u >= 0) C.contrib[u].push_back((uint32_t)(g * 64 + d));
         }
       };
       for (size_t ci = 0; ci < cl->bound.classes.size(); ++ci) {
@@ -1052,11 +1112,12 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   // lexicographic ranks of the special keys' values
   std::vector<uint16_t> vrank((size_t)std::max(nspec, 1) * 64, 0);
   for (int sp = 0; sp < nspec; ++sp) {
+    const LocalVocab& lvs = C.lv[C.spec_slot[sp]];
     const uint32_t key = C.slot_key[C.spec_slot[sp]];
-    std::vector<uint32_t> idx(V.vals[key].size());
+    std::vector<uint32_t> idx(lvs.size());
     for (size_t i = 0; i < idx.size(); ++i) idx[i] = (uint32_t)i;
-    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return V.vals[key].strs[a] < V.vals[key].strs[b]; });
-    for (size_t i = 0; i < idx.size() && idx[i] < 64; ++i) vrank[sp * 64 + idx[i]] = (uint16_t)i;
+    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return V.vals[key].strs[lvs.global(a)] < V.vals[key].strs[lvs.global(b)]; });
+    for (size_t i = 0; i < idx.size(); ++i) if (idx[i] < 64) vrank[sp * 64 + idx[i]] = (uint16_t)i;
   }
 
   KG_PROF("host ports (scheduling.HostPortUsage): t");
@@ -1151,8 +1212,10 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   std::vector<uint16_t> ktwv_n(std::max(Ka, 1), 0);
   for (int a = 0; a < Ka; ++a) {
     const uint32_t k = C.slot_key[a];
-    for (int w = 0; w < TW; ++w) { kU[(size_t)a * TW + w] = CT.kU[k][w]; kN[(size_t)a * TW + w] = CT.kN[k][w]; }
-    if (CT.key_row_off[k] != UINT32_MAX) { ktwv_off[a] = CT.key_row_off[k]; ktwv_n[a] = (uint16_t)CT.key_nvals[k]; }
+    // (a key first seen after the tables were built: no type mentions it)
+    const bool known = k < CT.key_row_off.size();
+    for (int w = 0; w < TW; ++w) { kU[(size_t)a * TW + w] = known ? CT.kU[k][w] : 0; kN[(size_t)a * TW + w] = known ? CT.kN[k][w] : CT.all_types[w]; }
+    if (known && CT.key_row_off[k] != UINT32_MAX) { ktwv_off[a] = CT.key_row_off[k]; ktwv_n[a] = (uint16_t)CT.key_nvals[k]; }
   }
 
   KG_PROF("pack the problem image");
@@ -1319,7 +1382,7 @@ static double cheapest_price(const CatType& t, uint64_t zmask, uint64_t ctmask) 
   double best = std::numeric_limits<double>::max();
   bool any = false;
   for (auto& o : t.offerings) {
-    if (!o.available || !((zmask >> o.zone) & 1) || !((ctmask >> o.ct) & 1)) continue;
+    if (!o.available || !((zmask >> o.lz) & 1) || !((ctmask >> o.lct) & 1)) continue;  // (masks over the catalog's own value numbering)
     if (!any || o.price < best) { best = o.price; any = true; }
   }
   return best;
@@ -1491,6 +1554,31 @@ int32_t kg_catalog_query(kg_catalog* cat, uint32_t type_index, const char* const
     name_buf[m] = 0;
   }
   return KG_OK;
+}
+
+int32_t kg_catalog_query_requirements(kg_catalog* cat, uint32_t type_index, char* buf, size_t cap, size_t* needed) {
+  if (!cat || type_index >= cat->types.size() || (!buf && cap)) return KG_EINVAL;
+  CtxLock lk(cat->ctx);
+  const Vocab& V = cat->ctx->V;
+  std::vector<std::string> lines;
+  for (auto& r : cat->types[type_index].reqs.rs) {
+    std::vector<std::string> vs;
+    for (uint32_t v : r.vals) vs.push_back(V.vals[r.key].strs[v]);
+    std::sort(vs.begin(), vs.end());
+    std::string l = V.keys.strs[r.key] + "\t" + (vs.empty() ? "DoesNotExist" : "In") + "\t";
+    for (size_t i = 0; i < vs.size(); ++i) l += (i ? "," : "") + vs[i];
+    lines.push_back(l + "\n");
+  }
+  std::sort(lines.begin(), lines.end());
+  std::string all;
+  for (auto& l : lines) all += l;
+  if (needed) *needed = all.size() + 1;
+  if (cap) {
+    const size_t m = std::min(cap - 1, all.size());
+    std::memcpy(buf, all.data(), m);
+    buf[m] = 0;
+  }
+  return cap >= all.size() + 1 ? KG_OK : KG_ENOMEM;
 }
 
 int32_t kg_catalog_update_offerings(kg_ctx* ctx, kg_catalog* cat, const kg_strtab* strings, const kg_offering_update* updates, uint32_t n_updates,
@@ -1730,7 +1818,8 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
       r.key = C->slot_key[a];
       r.compl_ = meta & RM_COMPL;
       for (int i = 0; i < C->aw[a]; ++i)
-        for (uint64_t m = c_bits[(size_t)(C->aoff[a] + i) * nclaims + c]; m; m &= m - 1) r.vals.push_back((uint32_t)(i * 64 + __builtin_ctzll(m)));
+        for (uint64_t m = c_bits[(size_t)(C->aoff[a] + i) * nclaims + c]; m; m &= m - 1) r.vals.push_back(C->lv[a].global((uint32_t)(i * 64 + __builtin_ctzll(m))));
+      std::sort(r.vals.begin(), r.vals.end());  // (HReq keeps context ids sorted)
       // bounds: indices refer to the per-slot sorted tables the compile built; recover the values from the device tables' host copy
       creqs.push_back(std::move(r));
       // (gt/lt filled below)
@@ -1745,12 +1834,13 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
         if (li) { creqs.back().has_lt = true; creqs.back().lt = lts[li - 1]; }
       }
     }
-    auto has_mask = [&](int slot) -> uint64_t {
+    auto has_mask = [&](int slot) -> uint64_t {  // allowed values of the claim on the key, over the catalog's value numbering
       if (slot < 0) return ~0ull;
       for (auto& r : creqs) {
         if (r.key != C->slot_key[slot]) continue;
+        const auto& cv = catalogs[0]->tab.cvals[r.key];
         uint64_t m = 0;
-        for (uint32_t v = 0; v < V.vals[r.key].size() && v < 64; ++v) if (r.has(V, v)) m |= 1ull << v;
+        for (uint32_t l = 0; l < cv.size() && l < 64; ++l) if (r.has(V, cv[l])) m |= 1ull << l;
         return m;
       }
       return ~0ull;
@@ -1873,7 +1963,7 @@ double worst_launch_price(const CatType& t, uint64_t zmask, uint64_t ctmask, int
     bool any = false;
     double worst = 0;
     for (auto& o : t.offerings) {
-      if (!o.available || (int)o.ct != want || !((zmask >> o.zone) & 1)) continue;
+      if (!o.available || (int)o.lct != want || !((zmask >> o.lz) & 1)) continue;
       if (!any || o.price > worst) { worst = o.price; any = true; }
     }
     if (any) return worst;
@@ -2119,7 +2209,9 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   }
   KG_PROF("cons: decisions");
   // ---- computeConsolidation's decision logic per simulation (prices are float64 catalog data: host side)
-  const int spot = V.vals[ctx->kCT].find("spot"), od = V.vals[ctx->kCT].find("on-demand");
+  // capacity types in the catalog's value numbering (ctmask bits, CatOffering::lct); gspot: the context id node labels carry
+  const int gspot = V.vals[ctx->kCT].find("spot"), god = V.vals[ctx->kCT].find("on-demand");
+  const int spot = gspot < 0 ? -1 : cat->tab.local(ctx->kCT, (uint32_t)gspot), od = god < 0 ? -1 : cat->tab.local(ctx->kCT, (uint32_t)god);
   std::unordered_map<std::string, int> type_by_name;
   for (size_t t = 0; t < cat->types.size(); ++t) type_by_name.emplace(cat->types[t].name, (int)t);
   std::vector<CandInfo> cinfo(n_used);
@@ -2133,7 +2225,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
       if (kv.first == ctx->kInstanceType) itv = (int)kv.second;
     }
     CandInfo& ci = cinfo[i];
-    ci.spot = ctv >= 0 && ctv == spot;
+    ci.spot = ctv >= 0 && ctv == gspot;
     if (itv < 0) continue;
     auto f = type_by_name.find(V.vals[ctx->kInstanceType].strs[itv]);
     if (f == type_by_name.end()) continue;
@@ -2338,11 +2430,12 @@ namespace {
 // zone / capacity-type admissible sets of a NodeClaim's requirements + its minValues, for price ordering
 void launch_view(kg_ctx* ctx, kg_catalog* cat, const HReqs& reqs, ClaimView* cv) {
   Vocab& V = ctx->V;
-  auto mask_of = [&](uint32_t key) -> uint64_t {
+  auto mask_of = [&](uint32_t key) -> uint64_t {  // over the catalog's value numbering
     const HReq* r = reqs.find(key);
     if (!r) return ~0ull;
     uint64_t m = 0;
-    for (uint32_t v = 0; v < V.vals[key].size() && v < 64; ++v) if (r->has(V, v)) m |= 1ull << v;
+    if (key < cat->tab.cvals.size())
+      for (uint32_t l = 0; l < cat->tab.cvals[key].size() && l < 64; ++l) if (r->has(V, cat->tab.cvals[key][l])) m |= 1ull << l;
     return m;
   };
   cv->zmask = mask_of(ctx->kZone);
@@ -2451,18 +2544,19 @@ int32_t kg_launch_filter(kg_ctx* ctx, kg_catalog* catalog, const kg_pools* pools
     }
     if (!generic.empty()) cv.types.swap(generic);
     // isMixedCapacityLaunch + filterUnwantedSpot
-    const int spot = V.vals[ctx->kCT].find("spot"), od = V.vals[ctx->kCT].find("on-demand");
+    const int gspot = V.vals[ctx->kCT].find("spot"), god = V.vals[ctx->kCT].find("on-demand");
+    const int spot = gspot < 0 ? -1 : catalog->tab.local(ctx->kCT, (uint32_t)gspot), od = god < 0 ? -1 : catalog->tab.local(ctx->kCT, (uint32_t)god);
     if (spot >= 0 && od >= 0 && ((cv.ctmask >> spot) & 1) && ((cv.ctmask >> od) & 1)) {
       bool has_spot = false, has_od = false;
       for (uint32_t t : cv.types)
         for (auto& o : catalog->types[t].offerings) {
-          if (!o.available || !((cv.zmask >> o.zone) & 1) || !((cv.ctmask >> o.ct) & 1)) continue;
-          if ((int)o.ct == spot) has_spot = true; else has_od = true;
+          if (!o.available || !((cv.zmask >> o.lz) & 1) || !((cv.ctmask >> o.lct) & 1)) continue;
+          if ((int)o.lct == spot) has_spot = true; else has_od = true;
         }
       if (has_spot && has_od) {
         double cheapest_od = std::numeric_limits<double>::max();
         for (uint32_t t : cv.types)
-          for (auto& o : catalog->types[t].offerings) if (o.available && (int)o.ct == od && o.price < cheapest_od) cheapest_od = o.price;
+          for (auto& o : catalog->types[t].offerings) if (o.available && (int)o.lct == od && o.price < cheapest_od) cheapest_od = o.price;
         std::vector<uint32_t> kept;
         for (uint32_t t : cv.types) {
           bool any = false;

@@ -14,7 +14,7 @@ DEFAULT_PATH = os.path.join(_HERE, "libkarpgpu.so")
 
 EXPORTS = ["kg_init", "kg_destroy", "kg_last_error", "kg_stats_get", "kg_catalog_upload", "kg_catalog_build_ec2", "kg_catalog_update_offerings", "kg_candidates_order", "kg_consolidate_validate",
            "kg_catalog_query", "kg_catalog_size", "kg_catalog_free", "kg_cluster_upload", "kg_cluster_free", "kg_solve",
-           "kg_truncate", "kg_launch_filter", "kg_consolidate_single", "kg_consolidate_multi", "kg_consolidate_select", "kg_solve_noalloc"]
+           "kg_truncate", "kg_launch_filter", "kg_consolidate_single", "kg_consolidate_multi", "kg_consolidate_select", "kg_solve_noalloc", "kg_catalog_query_requirements"]
 
 
 class KgError(RuntimeError):
@@ -92,6 +92,22 @@ class Library:
         if st != 0:
             raise KgError(st, "kg_catalog_query")
         return name.value.decode(), dict(zip(resources, cap)), dict(zip(resources, alloc))
+
+    def catalog_requirements(self, catalog, type_index):
+        """-> {label key: sorted value list} ([] = DoesNotExist) as the encoder holds them for the type."""
+        f = self.dll.kg_catalog_query_requirements
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        need = C.c_size_t(0)
+        f(catalog, type_index, None, 0, C.byref(need))
+        buf = C.create_string_buffer(need.value)
+        st = f(catalog, type_index, buf, need.value, C.byref(need))
+        if st != 0:
+            raise KgError(st, "kg_catalog_query_requirements")
+        out = {}
+        for line in buf.value.decode().splitlines():
+            k, op, vals = line.split("\t")
+            out[k] = vals.split(",") if op == "In" else []
+        return out
 
     def catalog_update_offerings(self, catalog, updates, generation):
         """updates: iterable of (type_index, zone, capacity_type, available or None, price or None)."""

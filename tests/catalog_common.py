@@ -9,7 +9,7 @@ RES = [co.RES_CPU, co.RES_MEM, co.RES_EPH, co.RES_PODS, co.RES_POD_ENI, co.RES_N
        co.RES_PRIVATE_IPV4]
 
 
-def _check_tables(L, infos, ctx, oz):
+def _check_tables(L, infos, ctx, oz, doc=None):
     types = co.list_instance_types(infos, ctx, ctx["limits"], ctx["bandwidth"], oz)
     h = L.catalog_build_ec2(abi.build_ec2_catalog(infos, ctx, ctx["limits"], ctx["bandwidth"], oz))
     try:
@@ -21,6 +21,13 @@ def _check_tables(L, infos, ctx, oz):
             for r in RES:
                 assert cap[r] == t["capacity"].get(r, 0), (name, r, cap[r], t["capacity"].get(r, 0))
                 assert alloc[r] == exp_alloc.get(r, 0), (name, r, alloc[r], exp_alloc.get(r, 0))
+            # computeRequirements (types.go:74-172), read back from the encoder: every key, every value, DoesNotExist entries
+            got = L.catalog_requirements(h, i)
+            assert got == {k: sorted(str(x) for x in v) for k, op, v in t["requirements"]}, (name, got)
+            # ... and directly against the labels the reference documents for the type (instance-types.md)
+            if doc is not None and name in doc:
+                for k, v in doc[name].items():
+                    assert got.get(k) == [v], (name, k, got.get(k), v)
     finally:
         L.dll.kg_catalog_free(h)
     return types
@@ -40,8 +47,10 @@ def check_ec2_build(L):
         dict(base, ami_family="Windows2022", pods_per_core=4),
         dict(base, ami_family="AL2023", instance_store_policy="RAID0", unavailable={("spot", infos[0]["InstanceType"], zones[0]), ("on-demand", infos[9]["InstanceType"], zones[2])}),
     ]
-    for ctx in variants:
-        types = _check_tables(L, infos, ctx, oz)
+    # the single-valued labels of the 776 documented rows (AL2023, the doc generator's node class = variant 0)
+    doc = {r["name"]: {k: v for k, v in r["labels"].items() if k != "karpenter.k8s.aws/instance-network-bandwidth" or True} for r in wl._load("instance_types_doc.json")}
+    for vi, ctx in enumerate(variants):
+        types = _check_tables(L, infos, ctx, oz, doc if vi == 0 else None)
     # behaviour: a Solve over the natively built catalog == a Solve over the uploaded oracle catalog
     ctx = variants[-1]
     types = co.list_instance_types(infos, ctx, ctx["limits"], ctx["bandwidth"], oz)

@@ -366,3 +366,40 @@ def scenario(name):
         small = wl.mixed_pods(500, 8, zones, families(types), prefix="small")
         return Problem(types, big + small, [wl.default_nodepool()])
     raise KeyError(name)
+
+
+def check_context_age(L):
+    """Kernel choice and limits depend on the batch and the catalog, not on what a long-lived context has seen: the context
+    first learns 80 zone names, 70 capacity-type names and 300 instance-family names from unrelated clusters and batches
+    (more than the 64 values a 1-word key holds, more than the 16 the single-wave kernel stages), then solves C2 on 3 zones:
+    same results as the oracle, served by the single-wave kernel."""
+    zones, types = catalog776()
+    fams = families(types)
+    t0 = [t for t in types if t["name"] == "m5.large"][0]
+    nodes = []
+    for i in range(300):
+        labels = {wl.L_ZONE: "zz-%02d" % (i % 80), wl.L_CT: "ct-%02d" % (i % 70), wl.L_HOSTNAME: "old-%03d" % i, wl.L_NODEPOOL: "default",
+                  wl.L_IT: "m5.large", wl.G + "/instance-family": "fam%03d" % i, wl.L_ARCH: "arch%d" % (i % 20)}
+        nodes.append({"name": "old-%03d" % i, "labels": labels, "taints": [], "available": {"cpu": 1000, "memory": wl.GI * 1000, "pods": 10000},
+                      "capacity": dict(t0["capacity"]), "daemon_requests": {}, "initialized": True, "managed": True, "deleting": False})
+    hcl = L.cluster_upload(abi.build_cluster(nodes, []))
+    L.dll.kg_cluster_free(hcl)
+    elsewhere = wl.mixed_pods(200, 77, zones, fams)
+    for i, p in enumerate(elsewhere):
+        p["node_selector"] = {wl.L_ZONE: "elsewhere-%02d" % (i % 40)}
+    prob = Problem(types, elsewhere, [wl.default_nodepool()])
+    assert diff_results(prob.run_oracle().decode(), prob.run_library(L).decode()) == ""
+    prob = Problem(types, wl.mixed_pods(2000, 42, zones, fams), [wl.default_nodepool()])
+    ro = prob.run_oracle()
+    L.set_collect_stats(False)
+    try:
+        w0 = L.stats().wave_solves
+        rg = prob.run_library(L)
+        assert L.stats().wave_solves == w0 + 1, "an aged context lost the single-wave kernel"
+    finally:
+        L.set_collect_stats(True)
+    d = diff_results(ro.decode(), rg.decode())
+    assert d == "", d
+    # topology over zones on the aged context (1-word key: at most 64 values IN THE BATCH)
+    p3 = scenario("c3_small")
+    assert diff_results(p3.run_oracle().decode(), p3.run_library(L).decode()) == ""

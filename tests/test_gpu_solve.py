@@ -134,12 +134,15 @@ def test_catalog_update_offerings_in_place(L):
 
 
 @pytest.fixture()
-def LW():
-    """A fresh context per test: the single-wave kernel applies while the context's vocabulary of 1-word keys (zones ...) is
-    small enough to stage in LDS, and a context shared with other tests accumulates every zone name they used."""
-    l = lib.Library()
-    yield l
-    l.close()
+def LW(L):
+    """The wave-kernel tests run on the module's long-lived context: kernel choice depends on the batch and the catalog
+    (solve-local value numbering), not on the label values earlier tests fed the context."""
+    return L
+
+
+def test_aged_context_keeps_the_wave_kernel(L):
+    from tests.helpers import check_context_age
+    check_context_age(L)
 
 
 def _check_wave(L, prob, expect_wave=True):

@@ -111,6 +111,11 @@ def test_feature_scenarios(L, name):
         assert ro.res.relaxations > 0
 
 
+def test_aged_context_keeps_the_wave_kernel(L):
+    from tests.helpers import check_context_age
+    check_context_age(L)
+
+
 def test_more_claims_than_the_lds_scan_order(L):
     """> 2048 NodeClaims in flight: the scan order moves from LDS to global memory mid-solve; both counter settings."""
     from tests.helpers import scenario

@@ -21,8 +21,16 @@ def apply_updates(types, updates):
         ty = out[t]
         live = [o for o in ty["offerings"] if o[4]]
         derived = {wl.L_ZONE: sorted({o[0] for o in live}), wl.L_CT: sorted({o[1] for o in live}), L_ZID: sorted({o[2] for o in live if o[2]})}
-        ty["requirements"] = [(k, op, derived[k]) if k in derived else (k, op, v) for k, op, v in ty["requirements"]]
+        reqs = [(k, op, derived[k]) if k in derived else (k, op, v) for k, op, v in ty["requirements"] if k != L_ZID]
+        if derived[L_ZID]:  # types.go:110-117: the zone-id requirement exists only while an available offering carries a zone id
+            reqs.append((L_ZID, "In", derived[L_ZID]))
+        ty["requirements"] = reqs
     return out
+
+
+def type_requirements(t):
+    """{key: sorted values} of a catalog type dict, the shape Library.catalog_requirements returns."""
+    return {k: sorted(str(x) for x in v) for k, op, v in t["requirements"]}
 
 
 def scenario_updates(types, zones):
@@ -62,6 +70,12 @@ def check_updates(L, n_pods=600):
         L.catalog_update_offerings(h, ups, generation=7)
         assert L.catalog_size(h)[1] == 7
         after = prob_a.run_library(L, h).decode()     # patched resident catalog
+        # the requirements the encoder holds for every touched type == computeRequirements over the rebuilt offerings: the
+        # all-ICE'd type lists no zone / capacity type and has lost its zone-id requirement
+        for t in sorted({u[0] for u in ups}):
+            assert L.catalog_requirements(h, t) == type_requirements(types_b[t]), types[t]["name"]
+        gone = [i for i, t in enumerate(types) if t["name"] == "c6i.large"][0]
+        assert L_ZID not in L.catalog_requirements(h, gone) and L.catalog_requirements(h, gone)[wl.L_ZONE] == []
         fresh = prob_b.run_library(L).decode()        # fresh upload of the rebuilt catalog
         oracle = prob_b.run_oracle().decode()
         assert diff_results(fresh, oracle) == ""
@@ -71,6 +85,8 @@ def check_updates(L, n_pods=600):
         undo = [(t, z, ct, True if av is not None else None, [o for o in types[t]["offerings"] if o[0] == z and o[1] == ct][0][3]) for t, z, ct, av, pr in ups]
         L.catalog_update_offerings(h, undo, generation=8)
         assert diff_results(before, prob_a.run_library(L, h).decode()) == ""
+        for t in sorted({u[0] for u in ups}):  # ... and to its first requirements: the zone-id requirement is back
+            assert L.catalog_requirements(h, t) == type_requirements(types[t]), types[t]["name"]
         st = L.stats()
         assert st.catalog_words_patched > 0
     finally:
