@@ -130,11 +130,12 @@ __global__ void __launch_bounds__(NT) k_simulate(DevProblem Pin, const SimState*
 // k_solve_wave: one WAVE = one Scheduler.Solve (solve_wave.hpp: batches without topology groups / existing nodes / minValues)
 template <bool DBG>
 __global__ void __launch_bounds__(64) k_solve_wave(DevProblem Pin, const SimState* sims, const uint32_t* nqueue) {
-  __shared__ Shared sh;
-  __shared__ uint64_t thr_lds[KG_THRROW_WORDS];
+  __shared__ SharedBase sh;
+  __shared__ __attribute__((aligned(16))) uint64_t pool[KG_POOL_WORDS];  // fit-threshold rows + prefilter records: the rest of the CU's 160 KiB
+  static_assert(sizeof(SharedBase) + sizeof(uint64_t) * KG_POOL_WORDS <= 160 * 1024, "LDS of one CU");
   const DevProblem& P = Pin;
   const SimState S = sims[blockIdx.x];
-  solve_wave<DBG>(P, S, sh, thr_lds, nqueue[blockIdx.x]);
+  solve_wave<DBG>(P, S, sh, pool, nqueue[blockIdx.x]);
 }
 
 // k_sim_init: one workgroup per simulation copies the pristine state image into its slot and applies the patches

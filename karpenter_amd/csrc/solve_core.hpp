@@ -247,8 +247,9 @@ struct PodCtx {
   uint64_t eam[KG_MAXE][KG_TWLDS];  // e_amask rows of the pod's requirement entries
 };
 static_assert(sizeof(PodCtx) % 8 == 0, "PodCtx is copied as 64-bit words");
+static_assert(sizeof(PodCtx) <= 4 * 64 * 8, "the single-wave kernel prefetches a pod context as four 8-byte words per lane");
 
-struct Shared {
+struct SharedBase {
   uint32_t best2[2], reason, pad0_;  // first feasible existing node (slot = placement parity); reasons of the pod being placed
   uint32_t thr_lds, tw_lds, off_lds, stw_lds;
   uint32_t fresh_lim[2];            // per template attempt (alternating): some instance type is within the limits
@@ -271,6 +272,10 @@ struct Shared {
   int64_t thr_val[KG_THR_LDS];
   // the in-flight NodeClaims in scan order (the reference's sorted slice), double-buffered: pod count << 32 | claim id
   unsigned long long ord[2][KG_ORD];
+};
+// ... plus the workgroup kernel's evaluation groups (the single-wave kernel keeps the claim row in registers and spends
+// the LDS on its prefilter records instead)
+struct Shared : SharedBase {
   Row rows[KG_MAXGP];                    // evaluation groups of the current pass
 };
 
@@ -1096,7 +1101,7 @@ __device__ __forceinline__ void fast_eval_wave(const DevProblem& P, const SimSta
 
 // ------------------------------------------------------------------ small problem tables -> LDS (start of every solve)
 template <int NT>
-KG_HD void stage_tables(const DevProblem& P, Shared& sh) {
+KG_HD void stage_tables(const DevProblem& P, SharedBase& sh) {
   // ---- stage the small problem tables in LDS
   KG_FOR_THREADS(tid, NT) {
     if (tid < KG_MAXR) {

@@ -30,9 +30,8 @@ struct LaneTabs {
   uint32_t spa, spoff;       // lane i < nspec: active slot of 1-word key i and its word offset in a claim row
   uint32_t tn, tbase, toff;  // lanes [8r, 8r + 8): number of fit thresholds of resource r, their base in sh.thr_val, in the catalog
 };
-constexpr uint32_t KG_THRROW_WORDS = 6144;  // fit-threshold rows ("types with allocatable >= v") staged in LDS by the single-wave solve: 48 KB
 template <bool FRESH>
-__device__ __forceinline__ bool wave_add(const DevProblem& P, const Shared& sh, const uint64_t* thr_rows, const LaneTabs& lt, const PodCtx& pc, uint32_t lane, uint32_t need,
+__device__ __forceinline__ bool wave_add(const DevProblem& P, const SharedBase& sh, const uint64_t* thr_rows, const LaneTabs& lt, const PodCtx& pc, uint32_t lane, uint32_t need,
                                          uint32_t tmpl, uint32_t& meta, uint64_t& bits, int64_t& req, uint64_t& m, bool* compat) {
   const uint32_t NR = (uint32_t)P.R, TW = (uint32_t)P.TW;
   const uint32_t rg = lane >> 3;
@@ -236,19 +235,32 @@ __device__ __forceinline__ uint64_t plain_set_or_all(uint32_t meta, uint64_t wor
   return ((meta & (RM_PRESENT | RM_COMPL)) == RM_PRESENT && word != 0) ? word : ~0ull;
 }
 
+// The prefilter part of the first `pfn` NodeClaims lives in LDS as well: record c = words [0..5] of the row (headroom x 4,
+// zone and capacity-type sets), the template, and the TW words of the option mask (rounded up to an even count: 16-byte
+// records).  A lane always reads sixteen mask words: the ones beyond the record belong to the next record and are cancelled
+// by the zero padding of the pod's own mask.  The records share one LDS pool with the fit-threshold rows; claims beyond `pfn`
+// are tested against their global rows as before.  What this buys is small (C2 k_solve_wave 52.1 -> 50.2 ms): measured,
+// a prefilter step is bound by the wave's own instruction stream, not by the round trip.  Tried and dropped: a 128-bit
+// folded signature instead of the mask (8 adjacent types per bit: instance families straddle the buckets, the false
+// survivors doubled the exact evaluations: 69 ms); whole rows in LDS with the per-pod results stored 64 at a time and the
+// next pod's context requested behind the prefilter (no global load or store left in a placement, but half as many
+// instructions again and twice the scalar-register spills: 54-55 ms).
+constexpr uint32_t KG_PF_HEAD = 8;  // words before the mask: h0..h3, zone, ct, template, pad
+constexpr uint32_t KG_POOL_WORDS = (160 * 1024 - (uint32_t)sizeof(SharedBase)) / 8 - 2;
+
 // scan order of the single-wave solve: one array, rotated in place (LDS while it fits, global memory beyond)
 constexpr uint32_t KG_WORD = 2 * KG_ORD;
 // (lds: every position in use is below KG_WORD -- a uniform fact the callers pass down, so that the common case has no
 // per-lane branch and no global load to wait for)
-__device__ __forceinline__ unsigned long long word_get(const SimState& S, const Shared& sh, bool lds, uint32_t p) {
+__device__ __forceinline__ unsigned long long word_get(const SimState& S, const SharedBase& sh, bool lds, uint32_t p) {
   if (lds || p < KG_WORD) { unsigned long long v = (&sh.ord[0][0])[lds ? (p & (KG_WORD - 1)) : p]; KG_OPAQUE64(v); return v; }
   return S.ordg[p];
 }
-__device__ __forceinline__ void word_set(const SimState& S, Shared& sh, bool lds, uint32_t p, unsigned long long v) {
+__device__ __forceinline__ void word_set(const SimState& S, SharedBase& sh, bool lds, uint32_t p, unsigned long long v) {
   if (lds || p < KG_WORD) (&sh.ord[0][0])[lds ? (p & (KG_WORD - 1)) : p] = v; else S.ordg[p] = v;
 }
 // end of the k-pod group: first position whose claim holds more than k pods (64-ary search)
-__device__ __forceinline__ uint32_t word_group_end(const SimState& S, const Shared& sh, bool lds, uint32_t nclaims, uint32_t k, uint32_t lane) {
+__device__ __forceinline__ uint32_t word_group_end(const SimState& S, const SharedBase& sh, bool lds, uint32_t nclaims, uint32_t k, uint32_t lane) {
   uint32_t stride = 1;
   while ((unsigned long long)stride * 64 < nclaims) stride *= 64;
   uint32_t lo = 0;
@@ -284,7 +296,7 @@ __device__ __forceinline__ void ctx_fetch_image(const DevProblem& P, PodCtx& nx,
 // nodes, no minValues, TW <= KG_TWLDS, every table stages into LDS, visit counters off.
 // DBG: with the per-section cycle accounting (its counters would otherwise cost the production kernel two dozen scalar registers)
 template <bool DBG>
-__device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& S, Shared& sh, uint64_t* thr_lds, uint32_t n_queue) {
+__device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& S, SharedBase& sh, uint64_t* pool, uint32_t n_queue) {
   const uint32_t lane = threadIdx.x & 63;
   // cycle accounting per section of a placement (stats & 8; debug): registers, written once at the end
   constexpr bool WT = DBG;
@@ -296,20 +308,27 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
   const uint32_t Ka = (uint32_t)P.Ka, Wa = (uint32_t)P.Wa, NR = (uint32_t)P.R, TW = (uint32_t)P.TW, NP = (uint32_t)P.NP;
   const size_t Cmax = (size_t)P.Cmax;
   const uint32_t rg = lane >> 3;
-  // the fit-threshold rows of the active resources, in the order of sh.thr_val, when they fit
+  // one LDS pool: the fit-threshold rows of the active resources (in the order of sh.thr_val) when they take at most
+  // half of it, then the prefilter records of as many NodeClaims as fit behind them
   const uint64_t* thr_rows = nullptr;
+  uint32_t pf_off = 0;
   {
     uint32_t tot = 0;
     for (uint32_t r = 0; r < NR; ++r) tot += sh.a_thr_n[r];
-    if (KG_UNI(tot) * TW <= KG_THRROW_WORDS) {
+    tot = KG_UNI(tot);
+    if (tot * TW <= KG_POOL_WORDS / 2) {
       for (uint32_t r = 0; r < NR; ++r) {
         const uint32_t n = KG_UNI(sh.a_thr_n[r]), b = KG_UNI(sh.thr_base[r]), o = KG_UNI(sh.a_thr_off[r]);
-        for (uint32_t i = lane; i < n * TW; i += 64) thr_lds[b * TW + i] = P.thr_mask[(size_t)o * TW + i];
+        for (uint32_t i = lane; i < n * TW; i += 64) pool[b * TW + i] = P.thr_mask[(size_t)o * TW + i];
       }
-      thr_rows = thr_lds;
+      thr_rows = pool;
+      pf_off = (tot * TW + 1) & ~1u;
       __syncthreads();
     }
   }
+  const uint32_t pfw = KG_PF_HEAD + ((TW + 1) & ~1u);                  // words per prefilter record
+  const uint32_t pfn = (KG_POOL_WORDS - pf_off - KG_TWLDS) / pfw;     // records that fit (a lane reads KG_TWLDS mask words whatever TW is)
+  uint64_t* const pf = pool + pf_off;
   LaneTabs lt;
   lt.spa = lt.spoff = lt.tn = lt.tbase = lt.toff = 0;
   if (lane < (uint32_t)P.nspec) { lt.spa = sh.spec_slot[lane]; lt.spoff = sh.aoff[lt.spa]; }
@@ -370,6 +389,7 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
     uint32_t reason = 0;
     bool placed = false;
     const bool lds = nclaims < KG_WORD;  // the scan order (with the claim this placement may add) fits LDS
+    const bool pf_all = nclaims <= pfn && lds;  // every claim's prefilter record (and the whole scan order) is in LDS
     KG_W(0);
     // the pod's side of the prefilter, in vector registers (the same value in every lane)
     int64_t prq[4];
@@ -380,7 +400,31 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
       const uint32_t pos = base + lane;
       bool ok = false;
       unsigned long long oe = 0;
-      if (pos < nclaims) {
+      if (pos < nclaims && pf_all) {
+        // every claim's prefilter record is in LDS: twelve 16-byte reads, no global round trip.  (The scan order is read
+        // directly: word_get's global alternative would make the compiler wait for every outstanding memory load here.)
+        oe = (&sh.ord[0][0])[pos];
+        KG_OPAQUE64(oe);
+        const uint32_t c = (uint32_t)oe;
+        const uint4* rec = (const uint4*)(pf + (size_t)c * pfw);
+        uint4 q[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) q[k] = rec[k];
+        const int64_t h0 = (int64_t)(((uint64_t)q[0].y << 32) | q[0].x), h1 = (int64_t)(((uint64_t)q[0].w << 32) | q[0].z);
+        const int64_t h2 = (int64_t)(((uint64_t)q[1].y << 32) | q[1].x), h3 = (int64_t)(((uint64_t)q[1].w << 32) | q[1].z);
+        const uint64_t czone = ((uint64_t)q[2].y << 32) | q[2].x, cct = ((uint64_t)q[2].w << 32) | q[2].z;
+        const uint32_t tm = q[3].x;
+        uint64_t any = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          any |= ((((uint64_t)q[4 + k].y << 32) | q[4 + k].x) & pc.podmask[2 * k]) | ((((uint64_t)q[4 + k].w << 32) | q[4 + k].z) & pc.podmask[2 * k + 1]);
+        }
+        uint32_t bad = (uint32_t)(((tolw >> tm) & 1) == 0) | (uint32_t)(any == 0) | (uint32_t)((czone & pzone) == 0) | (uint32_t)((cct & pct) == 0);
+        bad |= ((uint32_t)(h0 < prq[0]) & need) | ((uint32_t)(h1 < prq[1]) & (need >> 1)) | ((uint32_t)(h2 < prq[2]) & (need >> 2)) | ((uint32_t)(h3 < prq[3]) & (need >> 3));
+        bad &= 1u;
+        if (P.has_ports) bad |= (uint32_t)((S.c_ports[c] & hp_conf) != 0);
+        ok = hcok && bad == 0;
+      } else if (pos < nclaims) {
         oe = word_get(S, sh, lds, pos);
         const uint32_t c = (uint32_t)oe;
         // the claim's prefilter record: twelve 16-byte loads from consecutive addresses, one round trip
@@ -438,7 +482,7 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
             for (uint32_t r = 0; r < NR && r < 4; ++r) {
               const int64_t mx = wave_max_over_mask(P.alloc + (size_t)KG_UNI(sh.a_res[r]) * P.T, cm, TW, (uint32_t)P.T, lane);
               const int64_t rq = (int64_t)rl64((uint64_t)req0, 8 * r);
-              if (lane == 0) row[r] = (uint64_t)(mx - rq);
+              if (lane == 0) { row[r] = (uint64_t)(mx - rq); if (c < pfn) pf[(size_t)c * pfw + r] = (uint64_t)(mx - rq); }
             }
             if (lane == 0) row[7] = (uint64_t)stamp | ((uint64_t)stamp << 32);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the next survivor's loads may read this claim's lines)
@@ -460,6 +504,11 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
           const uint64_t n6 = (uint64_t)tm | ((uint64_t)(wnp + 1) << 32), n7 = (uint64_t)(seq + 1) | ((uint64_t)hst << 32);
           v = lane == 4 ? zw : (lane == 5 ? cw : (lane == 6 ? n6 : (lane == 7 ? n7 : v)));
           if (lane < 8) row[lane] = v;
+          if (c < pfn) {  // the LDS copy of the prefilter part (template unchanged)
+            uint64_t* rec = pf + (size_t)c * pfw;
+            if (lane < 6) rec[lane] = v;
+            if (lane < pfw - KG_PF_HEAD) rec[KG_PF_HEAD + lane] = m;  // (m is zero in lanes beyond TW)
+          }
         }
         if (lane == 0) {
           S.pod_kind[pod_row(S, pod)] = 2;
@@ -528,11 +577,18 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
           const uint64_t v = lane == 4 ? zw : (lane == 5 ? cw : (lane == 6 ? n6 : n7));
           if (lane >= NR && lane < 4) row[lane] = 0x7FFFFFFFFFFFFFFFull;  // (no such resource: never the reason to skip)
           if (lane >= 4 && lane < 8) row[lane] = v;
+          if (c < pfn) {
+            uint64_t* rec = pf + (size_t)c * pfw;
+            if (lane >= NR && lane < 4) rec[lane] = 0x7FFFFFFFFFFFFFFFull;
+            if (lane == 4 || lane == 5) rec[lane] = v;
+            if (lane == 6) rec[6] = (uint64_t)t;
+            if (lane < pfw - KG_PF_HEAD) rec[KG_PF_HEAD + lane] = m;
+          }
         }
         for (uint32_t r = 0; r < NR; ++r) {
           const int64_t mx = wave_max_over_mask(P.alloc + (size_t)KG_UNI(sh.a_res[r]) * P.T, m, TW, (uint32_t)P.T, lane);
           const int64_t rq = (int64_t)rl64((uint64_t)req, 8 * r);
-          if (lane == 0 && r < 4) row[r] = (uint64_t)(mx - rq);
+          if (lane == 0 && r < 4) { row[r] = (uint64_t)(mx - rq); if (c < pfn) pf[(size_t)c * pfw + r] = (uint64_t)(mx - rq); }
           // subtractMax: the worst-case capacity of the remaining options is charged against the limits
           if (P.tmpl_has_limits[t] && P.tmpl_limit_res[(size_t)r * NP + t]) {
             const int64_t cx = wave_max_over_mask(P.cap + (size_t)KG_UNI(sh.a_res[r]) * P.T, m, TW, (uint32_t)P.T, lane);
