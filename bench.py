@@ -31,15 +31,32 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
-def pmc_traffic(n_pods):
-    """HBM bytes per k_solve launch on this workload, from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE, each
-    its own run; gfx950 correction of MI355X_MICROARCH.md applied) -- counters cannot be read from inside the run.  None
-    for any workload other than the one profiled."""
-    path = os.path.join(ROOT, "profiles", "r01j_k_solve_wave_pmc.json")
-    if n_pods != 10000 or not os.path.exists(path):
-        return None
+PMC_FILE = os.path.join("profiles", "r02_pmc.json")
+
+
+def pmc_traffic(kernel, default_workload):
+    """HBM bytes per launch of `kernel` on the default workload, from the committed rocprofv3 PMC passes of this same
+    command (FETCH_SIZE, WRITE_SIZE, each its own run; gfx950 correction of MI355X_MICROARCH.md applied; made by
+    tools/gpu_round.sh + tools/pmc_summary.py) -- hardware counters cannot be read from inside the run.  -> (bytes or None,
+    source file or None); None for any workload other than the one profiled."""
+    path = os.path.join(ROOT, PMC_FILE)
+    if not default_workload or not os.path.exists(path):
+        return None, None
     with open(path) as f:
-        return json.load(f).get("k_solve_traffic_bytes")
+        k = json.load(f).get("kernels", {})
+    hit = [v for name, v in k.items() if name.split("<")[0].split("::")[-1] == kernel]
+    return (max(v["hbm_bytes_per_launch_corrected"] for v in hit), PMC_FILE) if hit else (None, None)
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def measured_copy_gbs(torch):
@@ -73,15 +90,26 @@ def bench_consolidation(args, L, hcat, types, zones, world, rank, barrier, dist,
     device = "cuda" if world > 1 else "cpu"
     out = {"workload": "C4: %d-node cluster (seed 11, ~12 pods/node, 35%% utilisation), %d bound pods, 0 pending" % (len(nodes), len(bound)),
            "scaling": "strong", "collective": "all_gather of %d-byte kg_candidate_record rows" % abi.CANDIDATE_RECORD.itemsize}
-    for multi in (False, True):
+    for multi in [m for m in (False, True) if args.cons in ("both", "multi" if m else "single")]:
+        # algorithmic bytes of one round (rows the reference visits, summed over this rank's simulations): one untimed round
+        # with the visit counters on
+        alg = 0.0
+        if not args.no_alg_bytes:
+            L.set_collect_stats(True)
+            distributed.consolidate(L, hcat, hcl, pend, nps, order, multi, device=device)
+            alg = L.stats().cons_algorithmic_bytes
+            L.set_collect_stats(False)
         for _ in range(args.warmup):
             distributed.consolidate(L, hcat, hcl, pend, nps, order, multi, device=device)
         barrier()
         t0 = time.perf_counter()
-        dms = []
+        dms, kms, ims = [], [], []
         for _ in range(args.steps):
             dec, n_local, ms = distributed.consolidate(L, hcat, hcl, pend, nps, order, multi, device=device)
+            st = L.stats()
             dms.append(ms)
+            kms.append(st.cons_simulate_ms)
+            ims.append(st.cons_sim_init_ms)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -89,10 +117,18 @@ def bench_consolidation(args, L, hcat, types, zones, world, rank, barrier, dist,
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         units = (min(len(order), 101) - 1) if multi else len(order)
+        k_ms = sum(kms) / len(kms)
+        achieved = alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic, src = pmc_traffic("k_simulate", args.nodes == 5000 and not multi and world == 1)
         out["multi_node" if multi else "single_node"] = {
             "value": units * args.steps / dt, "unit": "prefixes/s" if multi else "candidates/s", "units_per_round": units,
             "ms_per_round": dt * 1e3 / args.steps, "device_ms_per_round_rank0": sum(dms) / len(dms),
-            "decision": {k: dec[k] for k in ("decision", "n_candidates", "first_candidate")}}
+            "k_simulate_ms_rank0": k_ms, "k_sim_init_ms_rank0": sum(ims) / len(ims),
+            "decision": {k: dec[k] for k in ("decision", "n_candidates", "first_candidate")},
+            "roofline": {"bound": "hbm", "kernel": "k_simulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": alg,
+                         "note": "rank 0's simulations of one round: sum over simulations of 212 B x existing nodes visited + 400 B x "
+                                 "NodeClaims visited + 336 B x instance types filtered (SURVEY.md 8d) / HIP-event time of k_simulate"}}
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import loader
         k = min(30, len(order))
@@ -100,7 +136,7 @@ def bench_consolidation(args, L, hcat, types, zones, world, rank, barrier, dist,
         c0 = time.perf_counter()
         st, ro, _ = loader.consolidate_records([cat], cl, pend, nps, abi.build_candidates(order[:k]), False)
         ct = time.perf_counter() - c0
-        out["cpu_baseline"] = {"value": k / ct, "unit": "candidates/s", "cores": 1, "kind": "port",
+        out["cpu_baseline"] = {"value": k / ct, "unit": "candidates/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
                                "sample": "the first %d candidates of the same cluster, one oracle SimulateScheduling + computeConsolidation each" % k}
     L.dll.kg_cluster_free(hcl)
     return out
@@ -115,6 +151,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nodes", type=int, default=5000, help="C4 cluster size")
     ap.add_argument("--no-consolidation", action="store_true")
+    ap.add_argument("--cons", choices=("both", "single", "multi"), default="both", help="consolidation legs to run (profiling passes pick one)")
+    ap.add_argument("--no-alg-bytes", action="store_true", help="skip the untimed visit-counter rounds (profiling passes: every launch of a kernel is then the same work)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -144,8 +182,10 @@ def main():
 
     # algorithmic bytes (rows the reference visits) come from one untimed solve with the visit counters on;
     # the timed steps run with them off, as a production caller would
-    L.set_collect_stats(True)
-    alg_bytes = prob.run_library(L, hcat).res.algorithmic_bytes
+    alg_bytes = 0.0
+    if not args.no_alg_bytes:
+        L.set_collect_stats(True)
+        alg_bytes = prob.run_library(L, hcat).res.algorithmic_bytes
     L.set_collect_stats(False)
     for _ in range(args.warmup):
         prob.run_library(L, hcat)
@@ -175,6 +215,8 @@ def main():
         value = args.pods * world * args.steps / dt
         k_ms = sum(solve_ms) / len(solve_ms)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        kname = "k_solve_wave" if L.stats().wave_solves else "k_solve"
+        traffic, tsrc = pmc_traffic(kname, args.pods == 10000 and world == 1)
         out = {
             "metric": "pods/sec in Solve (10k pods x 750 types) + consolidation candidates/sec", "value": value, "unit": "pods/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -183,8 +225,8 @@ def main():
                                    % args.pods, "replicas": world, "n_claims": int(rb.res.n_claims)},
             "breakdown_ms": {"host_compile": sum(compile_ms) / len(compile_ms), "prepass_kernels": sum(pre_ms) / len(pre_ms),
                              "k_solve": k_ms, "host_decode_truncate": sum(decode_ms) / len(decode_ms)},
-            "roofline": {"bound": "hbm", "kernel": "k_solve_wave" if L.stats().wave_solves else "k_solve", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.pods),
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                          "peak_measured_copy": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "rows the reference algorithm visits up to its first feasible index (SURVEY.md 8d): "
@@ -193,15 +235,18 @@ def main():
         if cons is not None:
             out["consolidation"] = cons
         if not args.no_cpu_baseline:
-            # CPU oracle (oracle/oracle.cpp, -O2, one thread) on the same batch: 3 full Solves of the workload
+            # CPU oracle (oracle/oracle.cpp, -O2, one thread) on the same batch: 7 full Solves of the workload (~1 s each)
             times = []
-            for _ in range(3):
+            for _ in range(7):
                 c0 = time.perf_counter()
                 prob.run_oracle()
                 times.append(time.perf_counter() - c0)
             best = sorted(times)[len(times) // 2]
             out["cpu_baseline"] = {"value": args.pods / best, "unit": "pods/s", "cores": 1, "kind": "port",
-                                   "sample": "3 full Solves of the same %d-pod batch, median wall of ko_solve (descriptor parse included)" % args.pods}
+                                   "cpu_model": cpu_model(), "host_cores_visible": os.cpu_count(), "runs": len(times),
+                                   "sample": "7 full Solves of the same %d-pod batch, median wall of ko_solve (descriptor parse included), one thread" % args.pods,
+                                   "go_reference": "not run: no Go toolchain and no sigs.k8s.io/karpenter module on this box (BASELINE.md section 2)"}
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     L.dll.kg_catalog_free(hcat)
     L.close()

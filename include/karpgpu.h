@@ -356,6 +356,11 @@ typedef struct {
   uint64_t device_bytes_resident;
   uint64_t catalog_words_patched; /* 8-byte words of resident catalogs rewritten in place by kg_catalog_update_offerings */
   uint64_t wave_solves;           /* kg_solve calls served by the single-wave kernel (batches without topology groups / existing nodes / minValues) */
+  /* the last kg_consolidate_single / _multi call of the context */
+  uint64_t cons_simulations;      /* simulations run on the device (units with reschedulable pods) */
+  double cons_algorithmic_bytes;  /* SURVEY.md 8(d) bytes summed over the simulations; 0 unless the visit counters are on */
+  double cons_prepass_ms, cons_sim_init_ms, cons_simulate_ms, cons_gather_ms; /* HIP-event time per kernel group */
+  uint64_t cons_state_bytes_per_simulation;
 } kg_stats;
 
 typedef struct kg_ctx kg_ctx;

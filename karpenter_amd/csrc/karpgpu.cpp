@@ -2075,7 +2075,9 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   in.sim_cmax = cmax;
   in.universe_bound = &universe_bound;
   in.n_shared = n_shared;
-  auto C = compile_problem(in, false);
+  // (with the visit counters on, every simulation scans exactly and reports the rows the reference visits: bench.py's
+  // algorithmic bytes for the consolidation roofline; production callers switch them off)
+  auto C = compile_problem(in, ctx->collect_stats && !vout);
   const int N = C->N, NW = std::max((N + 63) / 64, 1), R = C->R, NP = C->NP;
   std::vector<int> pos_of_node(cluster->nodes.size(), -1);
   for (int i = 0; i < N; ++i) pos_of_node[C->node_order[i]] = i;
@@ -2091,7 +2093,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   KG_PROF("cons: prepass + batches");
   float ms_pre = 0;
   hal::launch_prepass(C->dp, C->pre, &ms_pre);
-  double ms_total = ms_pre;
+  double ms_total = ms_pre, ms_init = 0, ms_sim = 0, ms_gather = 0;
   const size_t stride = C->state_bytes;
   const size_t budget = (size_t)8 << 30;
   const size_t max_batch = std::max<size_t>(1, std::min<size_t>(live.size(), budget / stride > 1 ? budget / stride - 1 : 1));
@@ -2170,11 +2172,20 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
     hal::launch_sim_gather(C->dp, B, (const SimState*)pp(o_sims), &ms_g);
     hal::d2h(results.data() + b0, pp(o_res), nb * sizeof(SimResult));
     ms_total += ms_i + ms_s + ms_g;
+    ms_init += ms_i; ms_sim += ms_s; ms_gather += ms_g;
     ctx->stats.kernel_launches += 3;
     ctx->stats.solves += nb;
   }
   if (device_ms) *device_ms = ms_total;
   ctx->stats.device_ms_total += ms_total;
+  {
+    uint64_t v[4] = {0, 0, 0, 0};
+    for (auto& sr : results) for (int k = 0; k < 4; ++k) v[k] += sr.visited[k];
+    ctx->stats.cons_simulations = live.size();
+    ctx->stats.cons_algorithmic_bytes = 212.0 * v[0] + 400.0 * (v[1] + v[3]) + 336.0 * v[2];
+    ctx->stats.cons_prepass_ms = ms_pre; ctx->stats.cons_sim_init_ms = ms_init; ctx->stats.cons_simulate_ms = ms_sim; ctx->stats.cons_gather_ms = ms_gather;
+    ctx->stats.cons_state_bytes_per_simulation = stride;
+  }
 
   if (vout) {
     // validation: AllNonPendingPodsScheduled, and the NodeClaims Results.TruncateInstanceTypes leaves

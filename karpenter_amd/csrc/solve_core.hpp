@@ -1748,6 +1748,7 @@ struct SimResult {
   uint32_t zone_meta, ct_meta, zid_meta, pad;  // pad: claim 0 holds a pod that is being rescheduled (not a pending pod)
   uint64_t zone_word, ct_word, zid_word;
   uint64_t mask[KG_TWLDS];   // option mask of claim 0 (<= 1024 types)
+  uint64_t visited[4];       // rows the reference visits in this simulation (visit counters on): existing nodes, NodeClaims, their options, fresh-claim attempts
 };
 
 struct SimBatch {
@@ -1839,6 +1840,7 @@ KG_HD void sim_gather(const DevProblem& P, const SimBatch& B, const SimState& S,
     if (P.slot_ct >= 0) { const int a = P.spec_slot[P.slot_ct]; r.ct_meta = S.c_meta[(size_t)a * P.Cmax]; r.ct_word = S.c_bits[(size_t)P.aoff[a] * P.Cmax]; }
     if (P.slot_zid >= 0) { const int a = P.spec_slot[P.slot_zid]; r.zid_meta = S.c_meta[(size_t)a * P.Cmax]; r.zid_word = S.c_bits[(size_t)P.aoff[a] * P.Cmax]; }
   }
+  for (int k = 0; k < 4; ++k) r.visited[k] = S.counters[k];
   B.results[i] = r;
 }
 

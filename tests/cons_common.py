@@ -79,6 +79,13 @@ def check_consolidation(L, name, n, spot_to_spot, n_shards=3):
             assert len(a) == len(b)
             for x, y in zip(a, b):
                 assert x == y, (name, multi, x, y)
+            # (above: visit counters on = every simulation scans exactly; the production setting takes the prefilter path)
+            L.set_collect_stats(False)
+            try:
+                rp, _ = L.consolidate_records([hcat], hcl, pend, nps, cd, multi)
+            finally:
+                L.set_collect_stats(True)
+            assert [abi.record_tuple(r) for r in rp] == b, (name, multi, "prefilter path")
             seen.update(x[1] for x in a)
             # the shards' records, gathered, give the reference's sequential decision
             parts = [L.consolidate_records([hcat], hcl, pend, nps, abi.build_candidates(order, spot_to_spot=spot_to_spot, shard=s, n_shards=n_shards), multi)[0]

@@ -1,0 +1,19 @@
+#!/bin/bash
+# One GPU session of a round: parity suite, bench line, rocprofv3 kernel-trace summary, then counter passes (each its own
+# run, no trace flags): FETCH_SIZE, WRITE_SIZE (HBM traffic per launch) and one pass of 8 SQ counters, over a bench
+# command whose every launch of a kernel is the same work (C2 Solve + C4 single-node consolidation, no visit-counter rounds).
+set -o pipefail
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; TAG=${1:-r02a}
+cd $R
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > $O/pytest_gpu_$TAG.log 2>&1 || { tail -5 $O/pytest_gpu_$TAG.log; exit 1; }
+tail -2 $O/pytest_gpu_$TAG.log
+timeout -k 10 400 python -u bench.py > $O/bench_$TAG.json 2> $O/bench_$TAG.err || { tail -5 $O/bench_$TAG.err; exit 1; }
+cd /tmp && export TMPDIR=/tmp
+rm -rf $O/prof_$TAG $O/pmc_fetch_$TAG $O/pmc_write_$TAG $O/pmc_sq_$TAG
+PCMD="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --cons single --no-alg-bytes"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o $TAG --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/prof_$TAG.log 2>&1 || { tail -5 $O/prof_$TAG.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch_$TAG -o f --output-format csv -- $PCMD > $O/pmc_fetch_$TAG.log 2>&1 || { tail -5 $O/pmc_fetch_$TAG.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write_$TAG -o w --output-format csv -- $PCMD > $O/pmc_write_$TAG.log 2>&1 || { tail -5 $O/pmc_write_$TAG.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/pmc_sq_$TAG -o s --output-format csv -- $PCMD > $O/pmc_sq_$TAG.log 2>&1 || { tail -5 $O/pmc_sq_$TAG.log; exit 1; }
+find $O/prof_$TAG $O/pmc_fetch_$TAG $O/pmc_write_$TAG $O/pmc_sq_$TAG -name "*.csv" | head -20
+cat $O/bench_$TAG.json | cut -c1-1500
