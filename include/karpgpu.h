@@ -361,6 +361,7 @@ typedef struct {
   double cons_algorithmic_bytes;  /* SURVEY.md 8(d) bytes summed over the simulations; 0 unless the visit counters are on */
   double cons_prepass_ms, cons_sim_init_ms, cons_simulate_ms, cons_gather_ms; /* HIP-event time per kernel group */
   uint64_t cons_state_bytes_per_simulation;
+  uint64_t cons_plans_built, cons_plan_hits;  /* consolidation rounds that prepared their snapshot / found it prepared */
 } kg_stats;
 
 typedef struct kg_ctx kg_ctx;

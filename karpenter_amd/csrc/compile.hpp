@@ -74,4 +74,6 @@ struct kg_cluster {
   std::vector<kg::CNode> nodes;
   kg::ParsedPods bound;
   mutable std::vector<uint32_t> bound_rank;  // place of every bound pod in the Queue order among the bound pods (computed at first use)
+  std::vector<struct kg_cons_plan*> plans;    // consolidation plans built over this snapshot (karpgpu.cpp), least recently used dropped beyond 4
+  uint64_t plan_clock = 0;
 };

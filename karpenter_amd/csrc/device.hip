@@ -217,6 +217,7 @@ void dfree(void* p) { if (p) (void)hipFree(p); }
 void h2d(void* dst, const void* src, size_t bytes) { if (bytes) ck(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "hipMemcpy H2D"); }
 void d2h(void* dst, const void* src, size_t bytes) { if (bytes) ck(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost), "hipMemcpy D2H"); }
 void dzero(void* dst, size_t bytes) { if (bytes) ck(hipMemset(dst, 0, bytes), "hipMemset"); }
+void dfill(void* dst, int byte, size_t bytes) { if (bytes) ck(hipMemset(dst, byte, bytes), "hipMemset"); }
 
 // HIP-event bracket of one launch group; the events come from the device's pool (created at kg_init) and go back to it
 struct Timer {

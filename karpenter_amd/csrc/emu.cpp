@@ -20,6 +20,7 @@ void dfree(void* p) { std::free(p); }
 void h2d(void* dst, const void* src, size_t bytes) { if (bytes) std::memcpy(dst, src, bytes); }
 void d2h(void* dst, const void* src, size_t bytes) { if (bytes) std::memcpy(dst, src, bytes); }
 void dzero(void* dst, size_t bytes) { if (bytes) std::memset(dst, 0, bytes); }
+void dfill(void* dst, int byte, size_t bytes) { if (bytes) std::memset(dst, byte, bytes); }
 
 void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms) {
   auto t0 = std::chrono::steady_clock::now();

@@ -20,6 +20,7 @@ void dfree(void* p);
 void h2d(void* dst, const void* src, size_t bytes);
 void d2h(void* dst, const void* src, size_t bytes);
 void dzero(void* dst, size_t bytes);
+void dfill(void* dst, int byte, size_t bytes);  // debugging aid (KG_POISON): device memory filled with a byte pattern
 // k_type_filter + k_node_static + k_pod_mask
 void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms);
 // one workgroup per simulation; sims = DEVICE array of SimState

@@ -7,6 +7,7 @@
 // pkg/providers/instancetype/types.go:51-71 / instancetype.go:264-315.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -239,6 +240,9 @@ struct kg_ctx;
 struct kg_catalog {
   kg_ctx* ctx;
   uint64_t generation;
+  uint64_t tab_epoch = 0;  // bumped by every in-place update of the resident tables (consolidation plans are keyed on it)
+  uint64_t uid = next_uid();  // never reused within the process (a pointer is, after kg_catalog_free)
+  static uint64_t next_uid() { static std::atomic<uint64_t> n{1}; return n.fetch_add(1); }
   std::vector<kg::CatType> types;
   kg::CatalogTables tab;
 };

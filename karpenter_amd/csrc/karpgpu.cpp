@@ -8,6 +8,7 @@
 #include "compile.hpp"
 
 using namespace kg;
+void kg_cluster_drop_plans(kg_cluster* cl);
 using kgdesc::check;
 
 namespace kg {
@@ -320,6 +321,7 @@ struct Compiled {
   std::vector<std::vector<uint32_t>> contrib;
   std::vector<uint64_t> gdom_univ;   // [G] domains registered from the NodePools / instance types alone
   size_t o_nports, o_cports, o_crow = 0;  // o_crow: behind the state image (device-only, never uploaded)
+  size_t o_ntouch = 0, o_tnode = 0, o_tadd = 0, o_tports = 0;
   size_t o_nreq, o_creq, o_chead, o_chstamp, o_cmask, o_cbits, o_cmeta, o_cnpods, o_ctmpl, o_order, o_remaining, o_gcount, o_gdom, o_gpos, o_hcount, o_hpos, o_queue,
       o_podkind, o_excl, o_podindex, o_podreason, o_scratch, o_ordg, o_header, o_counters, o_nqueue;
   bool fixed = false;  // the device buffers are carved from a FixedArena (kg_solve_noalloc): nothing to give back
@@ -1229,7 +1231,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
                o_queue0 = A.add(queue0), o_lists = A.add(lists), o_tmplrs = A.add(tmpl_rs), o_tmplreq = A.add(tmpl_req),
                o_thl = A.add(tmpl_has_limits), o_tl0 = A.add(tmpl_limits0), o_tlr = A.add(tmpl_limit_res), o_toltmpl = A.add(tol_tmpl),
                o_minvoff = A.add(tmpl_minv_off), o_minvslot = A.add(minv_slot), o_minvmin = A.add(minv_min), o_navail = A.add(navail),
-               o_ntol = A.add(ntol), o_ndom = A.add(ndom), o_groups = A.add(dgroups),
+               o_ntol = A.add(ntol), o_ndom = A.add(ndom), o_groups = A.add(dgroups), o_nreq0 = A.add(nreq0), o_nports0 = A.add(nports0),
                o_filters = A.add(filters), o_nval = A.add(nval), o_rhm = A.add(rs_host_meta), o_rho = A.add(rs_host_off), o_rhn = A.add(rs_host_nodes);
   // kernel outputs (and the small table uploaded below) live behind the host image: never materialised on the host
   const size_t o_amask = A.reserve_tail((size_t)std::max(E, 1u) * TW * 8), o_podmask = A.reserve_tail((size_t)std::max(NV, 1) * TW * 8),
@@ -1289,6 +1291,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   D.cthr_val = (const int64_t*)cptr(CT.o_cthr_val); D.cthr_mask = (const uint64_t*)cptr(CT.o_cthr_mask); D.valid_types = (const uint64_t*)cptr(CT.o_valid);
   D.cap = (const int64_t*)cptr(CT.o_cap); D.alloc = (const int64_t*)cptr(CT.o_alloc); D.offmask = (const uint64_t*)cptr(CT.o_offmask); D.zone_zid = (const uint8_t*)cptr(CT.o_zone_zid);
   D.n_zone_vals = (int)CT.n_zone_vals; D.n_ct_vals = (int)CT.n_ct_vals;
+  D.sparse_nodes = sim_mode ? 1u : 0u; D.nreq0 = (const int64_t*)dptr(o_nreq0); D.nports0 = (const uint64_t*)dptr(o_nports0);
   D.navail = (const int64_t*)dptr(o_navail); D.nlab = (const uint64_t*)dptr(o_nlab); D.ntol = (const uint64_t*)dptr(o_ntol);
   D.ndom = (const uint16_t*)dptr(o_ndom); D.groups = (const Group*)dptr(o_groups); D.filters = (const uint32_t*)dptr(o_filters);
   PrepassTables& X = C.pre;
@@ -1302,8 +1305,12 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   std::vector<uint32_t> header(16, 0), nqueue{(uint32_t)P};
   std::vector<uint64_t> counters(64 + 16 * 32, 0);  // [64..): per-wave cycle accounting (16 waves x 16 slots)
   // initialised state first (it is what gets uploaded), per-claim / per-pod arrays behind it (zeroed on the device)
-  C.o_nreq = SA.add(nreq0);
-  C.o_nports = SA.add(nports0);
+  // existing nodes: one Solve keeps its own [R][N] requests / [N] port words; a simulation of a batch keeps a short list of
+  // the nodes it touched (behind the image) and a bit per node here
+  std::vector<uint64_t> ntouch0(NW, 0), excl0(NW, 0);
+  if (!sim_mode) { C.o_nreq = SA.add(nreq0); C.o_nports = SA.add(nports0); C.o_ntouch = 0; }
+  else { C.o_nreq = C.o_nports = 0; C.o_ntouch = SA.add(ntouch0); }
+  C.o_excl = SA.add(excl0);
   C.o_remaining = SA.add(remaining0);
   C.o_gcount = SA.add(gcount0); C.o_gdom = SA.add(gdom0); C.o_gpos = SA.add(gpos0); C.o_hcount = SA.add(hcount0); C.o_hpos = SA.add(hpos0);
   // Queue ring entries {pod, variant, lastLen epoch, lastLen value}
@@ -1331,12 +1338,13 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   C.o_podkind = SA.reserve_tail((size_t)PR);
   C.o_podindex = SA.reserve_tail((size_t)PR * 4);
   C.o_podreason = SA.reserve_tail((size_t)PR * 4);
-  C.o_excl = SA.reserve_tail((size_t)NW * 8);
+  C.o_tnode = SA.reserve_tail(sim_mode ? (size_t)Cmax * 4 : 8);
+  C.o_tadd = SA.reserve_tail(sim_mode ? (size_t)std::max(R, 1) * Cmax * 8 : 8);
+  C.o_tports = SA.reserve_tail(sim_mode ? (size_t)Cmax * 8 : 8);
   C.o_scratch = SA.reserve_tail((size_t)(TW + 1) * Cmax * 8);
   C.o_ordg = SA.reserve_tail((size_t)2 * Cmax * 8);
   C.state_bytes = SA.total();
-  if (sim_mode) SA.bytes.resize(C.state_bytes, 0);  // (the batches copy the whole pristine image into every simulation's slot)
-  else SA.bytes.resize(C.state_init_bytes, 0);
+  SA.bytes.resize(C.state_init_bytes, 0);  // (a batch copies this initialised prefix into every simulation's slot)
   C.state_image = std::move(SA.bytes);
   C.o_crow = C.state_bytes;
   if (sim_mode) return Cp;  // the caller lays out one slot per simulation
@@ -1367,6 +1375,7 @@ static SimState sim_at(const Compiled& C, uint8_t* base) {
   St.pod_index = (int32_t*)sptr(C.o_podindex); St.pod_reason = (uint32_t*)sptr(C.o_podreason); St.scratch = (uint64_t*)sptr(C.o_scratch);
   St.header = (uint32_t*)sptr(C.o_header); St.counters = (uint64_t*)sptr(C.o_counters);
   St.excl = (const uint64_t*)sptr(C.o_excl); St.ordg = (unsigned long long*)sptr(C.o_ordg);
+  St.ntouch = (uint64_t*)sptr(C.o_ntouch); St.tnode = (uint32_t*)sptr(C.o_tnode); St.tadd = (int64_t*)sptr(C.o_tadd); St.tports = (uint64_t*)sptr(C.o_tports);
   St.n_shared = (uint32_t)C.P; St.pod_base = 0; St.qcap = C.qcap;
   return St;
 }
@@ -1588,6 +1597,7 @@ int32_t kg_catalog_update_offerings(kg_ctx* ctx, kg_catalog* cat, const kg_strta
   KG_GUARD_BEGIN
   update_offerings(ctx, cat, *strings, updates, n_updates);
   cat->generation = generation;
+  cat->tab_epoch += 1;
   return KG_OK;
   KG_GUARD_END(ctx)
 }
@@ -1638,6 +1648,10 @@ int32_t kg_cluster_upload(kg_ctx* ctx, const kg_cluster_desc* desc, kg_cluster**
 }
 
 int32_t kg_cluster_free(kg_cluster* cl) {
+  if (cl) {
+    CtxLock lk(cl->ctx);  // (the plans' device buffers are freed on the context's GPU)
+    kg_cluster_drop_plans(cl);
+  }
   delete cl;
   return KG_OK;
 }
@@ -1986,24 +2000,67 @@ struct ValidateOut {
   std::vector<uint32_t> types;    // options of the one NodeClaim, truncated
 };
 
-static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, kg_cluster* cluster, const kg_pods_desc* pending,
-                                const kg_nodepools_desc* nodepools, const kg_candidates_desc* cands, bool multi, kg_candidate_record* records,
-                                uint32_t cap_records, uint32_t* n_records, double* device_ms, ValidateOut* vout = nullptr) {
-  if (!ctx || !catalogs || n_catalogs == 0 || !cluster || !nodepools || !cands || !n_records || (!records && cap_records)) return KG_EINVAL;
-  CtxLock lk(ctx);
-  KG_GUARD_BEGIN
-  if (n_catalogs != 1) throw Unsupported("one catalog per solve on the device path");
-  kg_catalog* cat = catalogs[0];
-  Vocab& V = ctx->V;
-  const uint32_t n = cands->n_candidates;
-  const int shards = std::max(cands->n_shards, 1);
-  check(cands->shard >= 0 && cands->shard < shards, "shard index");
-  for (uint32_t i = 0; i < n; ++i) check(cands->candidates[i] >= 0 && cands->candidates[i] < (int)cluster->nodes.size(), "candidate node index");
-  *n_records = 0;
-  if (device_ms) *device_ms = 0;
+// ------------------------------------------------------------------ consolidation plans
+// Everything of a consolidation round that does not depend on the shard or on the call: the pod universe, the compiled
+// problem (resident on the device), the queue / excluded-node / limit / topology patches of EVERY unit (resident too), the
+// candidates' prices.  Built once per (cluster snapshot, catalog generation, NodePools, pending pods, candidate order, mode)
+// and kept with the kg_cluster; a round that finds its plan only launches the three kernels over its shard's units and runs
+// the price logic on what comes back.  (Round 1 rebuilt all of it in every call on every rank: 6 of 8 ms on C4.)
+namespace {
+struct Hasher {
+  uint64_t h = 1469598103934665603ull;
+  void bytes(const void* p, size_t n) {
+    const uint8_t* b = (const uint8_t*)p;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t w; std::memcpy(&w, b + i, 8); h = (h ^ w) * 1099511628211ull; h ^= h >> 29; }
+    for (; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+  }
+  void u64(uint64_t v) { bytes(&v, 8); }
+  template <class T> void arr(const T* p, size_t n) { u64(n); if (n && p) bytes(p, n * sizeof(T)); }
+  void pools(const kg_pools& p) {
+    u64(p.strings.count);
+    if (p.strings.count) { arr(p.strings.offsets, p.strings.count + 1); arr(p.strings.data, p.strings.offsets[p.strings.count]); }
+    arr(p.reqs, p.n_reqs); arr(p.req_values, p.n_req_values); arr(p.quantities, p.n_quantities); arr(p.labels, p.n_labels);
+    arr(p.taints, p.n_taints); arr(p.tolerations, p.n_tolerations); arr(p.ranges, p.n_ranges);
+  }
+};
+}  // namespace
 
+struct ConsUnit { uint32_t id, pod_lo, pod_hi; bool skip; };
+struct kg_cons_plan {
+  uint64_t key = 0;
+  bool multi = false;
+  uint32_t n = 0, n_used = 0, n_shared = 0;
+  std::vector<int32_t> candidates;
+  std::vector<uint32_t> cand_begin;
+  std::vector<ConsUnit> units;  // every unit of the mode (single: candidate u; multi: prefix [0..u]), index = u - lo
+  std::unique_ptr<Compiled> C;
+  bool any_limits = false;
+  DeviceBuffer tables;          // per-unit patches of every unit + the universe's flags
+  size_t o_qoff = 0, o_qent = 0, o_xoff = 0, o_xnode = 0, o_rem = 0, o_np = 0, o_un = 0, o_toff = 0, o_tent = 0, o_guniv = 0;
+  std::vector<CandInfo> cinfo;  // getCandidatePrices inputs per candidate
+  int spot = -1, od = -1;
+  float ms_prepass = 0;
+  // the shard last run: its live units, their state slots and launch tables (kept: the next round of the same shard reuses them)
+  int shard = -1, n_shards = 0;
+  std::vector<uint32_t> live;   // unit indices
+  DeviceBuffer arena, run;
+  size_t max_batch = 0, o_sims = 0, o_unit = 0, o_nq = 0, o_res = 0;
+  uint64_t last_use = 0;
+  ~kg_cons_plan() { hal::dfree(tables.ptr); hal::dfree(arena.ptr); hal::dfree(run.ptr); }
+};
+void kg_cluster_drop_plans(kg_cluster* cl) { for (auto* p : cl->plans) delete p; cl->plans.clear(); }
+
+static std::unique_ptr<kg_cons_plan> build_cons_plan(kg_ctx* ctx, kg_catalog* cat, kg_cluster* cluster, const kg_pods_desc* pending,
+                                                     const kg_nodepools_desc* nodepools, const kg_candidates_desc* cands, bool multi, bool validate) {
   HostProf prof_;
-  KG_PROF("cons: pod universe");
+  Vocab& V = ctx->V;
+  auto Pp = std::make_unique<kg_cons_plan>();
+  kg_cons_plan& PL = *Pp;
+  PL.multi = multi || validate;  // (a validated command is a prefix: every candidate of it is taken out of the cluster)
+  const uint32_t n = cands->n_candidates;
+  PL.n = n;
+  KG_PROF("plan: pod universe");
   // ---- pod universe: pending pods, pods of deleting nodes, then the candidates' reschedulable pods in candidate order
   ParsedPods pend;
   parse_pods(ctx, pending, &pend, true);
@@ -2032,44 +2089,36 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   std::vector<uint8_t> is_cand(cluster->nodes.size(), 0);
   // multi: firstNConsolidationOption gets max = Clamp(len, 0, 100) and only lowers it to len - 1 when len <= max, so with more than
   // 100 candidates the binary search probes mid in [1, 100] and the longest prefix is candidates[0:101]
-  const uint32_t n_used = multi ? std::min<uint32_t>(n, 101) : n;
+  const uint32_t n_used = (multi && !validate) ? std::min<uint32_t>(n, 101) : n;
+  PL.n_used = n_used;
+  PL.candidates.assign(cands->candidates, cands->candidates + n_used);
   for (uint32_t i = 0; i < n_used; ++i) is_cand[cands->candidates[i]] = 1;
   for (size_t nd = 0; nd < cluster->nodes.size(); ++nd)
     if (cluster->nodes[nd].deleting && !is_cand[nd]) for (uint32_t bi : pods_of_node[nd]) add_bound(bi);
   const uint32_t n_shared = (uint32_t)U.pods.size();
-  std::vector<uint32_t> cand_begin(n_used + 1, n_shared);
+  PL.n_shared = n_shared;
+  std::vector<uint32_t>& cand_begin = PL.cand_begin;
+  cand_begin.assign(n_used + 1, n_shared);
   for (uint32_t i = 0; i < n_used; ++i) {
     cand_begin[i] = (uint32_t)U.pods.size();
     for (uint32_t bi : pods_of_node[cands->candidates[i]]) add_bound(bi);
   }
   cand_begin[n_used] = (uint32_t)U.pods.size();
 
-  KG_PROF("cons: units");
-  // ---- units of this shard
-  struct Unit { uint32_t id; uint32_t pod_lo, pod_hi; bool skip; };
-  std::vector<Unit> units;
+  KG_PROF("plan: units");
   const uint32_t lo = multi ? 1 : 0, hi = multi ? n_used : n;
-  if (vout && n_used > 0) units.push_back(Unit{n_used - 1, n_shared, cand_begin[n_used], false});  // one simulation: every candidate of the command
-  for (uint32_t u = lo; u < hi && !vout; ++u) {
-    if ((int)((u - lo) % shards) != cands->shard) continue;
-    Unit un{u, multi ? n_shared : cand_begin[u], cand_begin[u + 1], false};
+  if (validate) { if (n_used > 0) PL.units.push_back(ConsUnit{n_used - 1, n_shared, cand_begin[n_used], false}); }  // one simulation: every candidate of the command
+  else for (uint32_t u = lo; u < hi; ++u) {
+    ConsUnit un{u, multi ? n_shared : cand_begin[u], cand_begin[u + 1], false};
     if (!multi && un.pod_hi == un.pod_lo) un.skip = true;  // no reschedulable pods: emptiness handles the node
-    units.push_back(un);
+    PL.units.push_back(un);
   }
-  *n_records = (uint32_t)units.size();
-  if (units.size() > cap_records) return fail(ctx, KG_ENOMEM, "record buffer too small");
-  for (size_t k = 0; k < units.size(); ++k) {
-    std::memset(&records[k], 0, sizeof(kg_candidate_record));
-    records[k].candidate = (int32_t)units[k].id;
-  }
-  std::vector<uint32_t> live;
   int cmax = 1;
-  for (size_t k = 0; k < units.size(); ++k)
-    if (!units[k].skip) { live.push_back((uint32_t)k); cmax = std::max(cmax, (int)(n_shared + units[k].pod_hi - units[k].pod_lo)); }
-  if (live.empty()) return KG_OK;
-  if (vout) multi = true;  // (the unit is a prefix: every candidate up to its id is taken out of the cluster)
+  bool any_live = false;
+  for (auto& un : PL.units) if (!un.skip) { any_live = true; cmax = std::max(cmax, (int)(n_shared + un.pod_hi - un.pod_lo)); }
+  if (!any_live) return Pp;
 
-  KG_PROF("cons: compile_problem");
+  KG_PROF("plan: compile_problem");
   // ---- compile once; every simulation shares the problem tables
   SolveInputs in{ctx, cat, cluster, nodepools, &U};
   in.sim_cmax = cmax;
@@ -2077,7 +2126,8 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   in.n_shared = n_shared;
   // (with the visit counters on, every simulation scans exactly and reports the rows the reference visits: bench.py's
   // algorithmic bytes for the consolidation roofline; production callers switch them off)
-  auto C = compile_problem(in, ctx->collect_stats && !vout);
+  PL.C = compile_problem(in, ctx->collect_stats && !validate);
+  Compiled* C = PL.C.get();
   const int N = C->N, NW = std::max((N + 63) / 64, 1), R = C->R, NP = C->NP;
   std::vector<int> pos_of_node(cluster->nodes.size(), -1);
   for (int i = 0; i < N; ++i) pos_of_node[C->node_order[i]] = i;
@@ -2087,95 +2137,230 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   for (int i = 0; i < N; ++i) if (!cluster->nodes[C->node_order[i]].initialized) node_uninit[i >> 6] |= 1ull << (i & 63);
   bool any_limits = false;
   for (auto& tp : C->templates) any_limits |= tp.has_limits && !tp.limits.empty();
+  PL.any_limits = any_limits;
   std::vector<int> ract(V.resources.size(), -1);
   for (int r = 0; r < R; ++r) ract[C->act_res[r]] = r;
+  hal::launch_prepass(C->dp, C->pre, &PL.ms_prepass);
 
-  KG_PROF("cons: prepass + batches");
-  float ms_pre = 0;
-  hal::launch_prepass(C->dp, C->pre, &ms_pre);
-  double ms_total = ms_pre, ms_init = 0, ms_sim = 0, ms_gather = 0;
-  const size_t stride = C->state_bytes;
-  const size_t budget = (size_t)8 << 30;
-  const size_t max_batch = std::max<size_t>(1, std::min<size_t>(live.size(), budget / stride > 1 ? budget / stride - 1 : 1));
-  std::vector<SimResult> results(live.size());
-  for (size_t b0 = 0; b0 < live.size(); b0 += max_batch) {
-    const size_t nb = std::min(max_batch, live.size() - b0);
-    std::vector<uint32_t> q_off(nb + 1, 0), x_off(nb + 1, 0), x_node, t_off(nb + 1, 0), t_ent;
-    std::vector<uint32_t> q_ent;
-    std::vector<int64_t> rem_adj(any_limits ? nb * (size_t)R * NP : 0, 0);
-    std::vector<SimState> sims(nb);
-    DeviceBuffer arena;
-    arena.bytes = (nb + 1) * stride;
-    arena.ptr = hal::dmalloc(arena.bytes);
-    struct Free { void* p; ~Free() { hal::dfree(p); } } free_arena{arena.ptr};
-    hal::h2d(arena.ptr, C->state_image.data(), stride);
-    for (size_t k = 0; k < nb; ++k) {
-      const Unit& un = units[live[b0 + k]];
-      std::vector<uint32_t> pods;
-      for (uint32_t p = 0; p < n_shared; ++p) pods.push_back(p);
-      for (uint32_t p = un.pod_lo; p < un.pod_hi; ++p) pods.push_back(p);
-      std::sort(pods.begin(), pods.end(), [&](uint32_t a, uint32_t b) { return rank[a] < rank[b]; });
-      q_off[k] = (uint32_t)(q_ent.size() / 4);
-      for (uint32_t p : pods) { q_ent.push_back(p); q_ent.push_back(C->pod_variant0[p]); q_ent.push_back(0); q_ent.push_back(0); }
-      x_off[k] = (uint32_t)x_node.size();
-      t_off[k] = (uint32_t)t_ent.size();
-      if (!C->contrib.empty())
-        for (uint32_t p = un.pod_lo; p < un.pod_hi; ++p) t_ent.insert(t_ent.end(), C->contrib[p].begin(), C->contrib[p].end());
-      const uint32_t c0 = multi ? 0 : un.id, c1 = un.id + 1;
-      for (uint32_t ci = c0; ci < c1; ++ci) {
-        const int nd = cands->candidates[ci];
-        if (pos_of_node[nd] >= 0) x_node.push_back((uint32_t)pos_of_node[nd]);
-        if (any_limits && pos_of_node[nd] >= 0) {
-          // the scheduler of a simulation does not charge the candidates against their NodePool's limits
-          uint32_t npv = UINT32_MAX;
-          for (auto& kv : cluster->nodes[nd].labels) if (kv.first == ctx->kNodePool) npv = kv.second;
-          if (npv == UINT32_MAX) continue;
-          for (int t = 0; t < NP; ++t) {
-            const auto& tp = C->templates[t];
-            if (!(tp.has_limits && !tp.limits.empty()) || V.vals[ctx->kNodePool].strs[npv] != tp.name) continue;
-            for (auto& kv : cluster->nodes[nd].capacity) {
-              bool limited = false;
-              for (auto& lv : tp.limits) limited |= lv.first == kv.first;
-              if (limited && ract[kv.first] >= 0) rem_adj[k * (size_t)R * NP + (size_t)ract[kv.first] * NP + t] += kv.second;
-            }
+  KG_PROF("plan: per-unit patches");
+  // ---- the patches of every unit: its queue (the universe's Queue order restricted to its pods), the candidate nodes it
+  // leaves out, the limits they give back, the topology counts of the pods it reschedules
+  const size_t nu = PL.units.size();
+  std::vector<uint32_t> q_off(nu + 1, 0), x_off(nu + 1, 0), x_node, t_off(nu + 1, 0), t_ent, q_ent;
+  std::vector<int64_t> rem_adj(any_limits ? nu * (size_t)R * NP : 0, 0);
+  std::vector<uint32_t> shared_sorted;
+  for (uint32_t p = 0; p < n_shared; ++p) shared_sorted.push_back(p);
+  std::sort(shared_sorted.begin(), shared_sorted.end(), [&](uint32_t a, uint32_t b) { return rank[a] < rank[b]; });
+  std::vector<uint32_t> own, pods;
+  for (size_t k = 0; k < nu; ++k) {
+    const ConsUnit& un = PL.units[k];
+    q_off[k] = (uint32_t)(q_ent.size() / 4);
+    x_off[k] = (uint32_t)x_node.size();
+    t_off[k] = (uint32_t)t_ent.size();
+    if (un.skip) continue;
+    own.clear();
+    for (uint32_t p = un.pod_lo; p < un.pod_hi; ++p) own.push_back(p);
+    std::sort(own.begin(), own.end(), [&](uint32_t a, uint32_t b) { return rank[a] < rank[b]; });
+    pods.resize(shared_sorted.size() + own.size());
+    std::merge(shared_sorted.begin(), shared_sorted.end(), own.begin(), own.end(), pods.begin(), [&](uint32_t a, uint32_t b) { return rank[a] < rank[b]; });
+    for (uint32_t p : pods) { q_ent.push_back(p); q_ent.push_back(C->pod_variant0[p]); q_ent.push_back(0); q_ent.push_back(0); }
+    if (!C->contrib.empty())
+      for (uint32_t p = un.pod_lo; p < un.pod_hi; ++p) t_ent.insert(t_ent.end(), C->contrib[p].begin(), C->contrib[p].end());
+    const uint32_t c0 = PL.multi ? 0 : un.id, c1 = un.id + 1;
+    for (uint32_t ci = c0; ci < c1; ++ci) {
+      const int nd = cands->candidates[ci];
+      if (pos_of_node[nd] >= 0) x_node.push_back((uint32_t)pos_of_node[nd]);
+      if (any_limits && pos_of_node[nd] >= 0) {
+        // the scheduler of a simulation does not charge the candidates against their NodePool's limits
+        uint32_t npv = UINT32_MAX;
+        for (auto& kv : cluster->nodes[nd].labels) if (kv.first == ctx->kNodePool) npv = kv.second;
+        if (npv == UINT32_MAX) continue;
+        for (int t = 0; t < NP; ++t) {
+          const auto& tp = C->templates[t];
+          if (!(tp.has_limits && !tp.limits.empty()) || V.vals[ctx->kNodePool].strs[npv] != tp.name) continue;
+          for (auto& kv : cluster->nodes[nd].capacity) {
+            bool limited = false;
+            for (auto& lv : tp.limits) limited |= lv.first == kv.first;
+            if (limited && ract[kv.first] >= 0) rem_adj[k * (size_t)R * NP + (size_t)ract[kv.first] * NP + t] += kv.second;
           }
         }
       }
-      sims[k] = sim_at(*C, (uint8_t*)arena.ptr + (k + 1) * stride);
-      sims[k].n_shared = n_shared;
-      sims[k].pod_base = un.pod_lo;
     }
-    q_off[nb] = (uint32_t)(q_ent.size() / 4);
-    x_off[nb] = (uint32_t)x_node.size();
-    t_off[nb] = (uint32_t)t_ent.size();
-    // one upload for all the per-simulation tables
+  }
+  q_off[nu] = (uint32_t)(q_ent.size() / 4);
+  x_off[nu] = (uint32_t)x_node.size();
+  t_off[nu] = (uint32_t)t_ent.size();
+  {
     Arena PA;
-    const size_t o_qoff = PA.add(q_off), o_qent = PA.add(q_ent, 4), o_xoff = PA.add(x_off), o_xnode = PA.add(x_node), o_rem = PA.add(rem_adj),
-                 o_nq = PA.reserve(nb * 4), o_res = PA.reserve(nb * sizeof(SimResult)), o_np = PA.add(nonpending), o_un = PA.add(node_uninit),
-                 o_sims = PA.add(sims), o_toff = PA.add(t_off), o_tent = PA.add(t_ent), o_guniv = PA.add(C->gdom_univ);
-    DeviceBuffer patch;
-    patch.bytes = PA.bytes.size();
-    patch.ptr = hal::dmalloc(patch.bytes);
-    Free free_patch{patch.ptr};
-    hal::h2d(patch.ptr, PA.bytes.data(), patch.bytes);
-    auto pp = [&](size_t off) { return (uint8_t*)patch.ptr + off; };
+    PL.o_qoff = PA.add(q_off); PL.o_qent = PA.add(q_ent, 4); PL.o_xoff = PA.add(x_off); PL.o_xnode = PA.add(x_node); PL.o_rem = PA.add(rem_adj);
+    PL.o_np = PA.add(nonpending); PL.o_un = PA.add(node_uninit); PL.o_toff = PA.add(t_off); PL.o_tent = PA.add(t_ent); PL.o_guniv = PA.add(C->gdom_univ);
+    PL.tables.bytes = PA.bytes.size();
+    PL.tables.ptr = hal::dmalloc(PL.tables.bytes);
+    hal::h2d(PL.tables.ptr, PA.bytes.data(), PL.tables.bytes);
+  }
+
+  KG_PROF("plan: candidate prices");
+  // capacity types in the catalog's value numbering (ctmask bits, CatOffering::lct); gspot: the context id node labels carry
+  const int gspot = V.vals[ctx->kCT].find("spot"), god = V.vals[ctx->kCT].find("on-demand");
+  PL.spot = gspot < 0 ? -1 : cat->tab.local(ctx->kCT, (uint32_t)gspot);
+  PL.od = god < 0 ? -1 : cat->tab.local(ctx->kCT, (uint32_t)god);
+  std::unordered_map<std::string, int> type_by_name;
+  for (size_t t = 0; t < cat->types.size(); ++t) type_by_name.emplace(cat->types[t].name, (int)t);
+  PL.cinfo.assign(n_used, CandInfo());
+  for (uint32_t i = 0; i < n_used; ++i) {
+    const CNode& nd = cluster->nodes[cands->candidates[i]];
+    int zone = -1, ctv = -1, zid = -1, itv = -1;
+    for (auto& kv : nd.labels) {
+      if (kv.first == ctx->kZone) zone = (int)kv.second;
+      if (kv.first == ctx->kCT) ctv = (int)kv.second;
+      if (kv.first == ctx->kZid) zid = (int)kv.second;
+      if (kv.first == ctx->kInstanceType) itv = (int)kv.second;
+    }
+    CandInfo& ci = PL.cinfo[i];
+    ci.spot = ctv >= 0 && ctv == gspot;
+    if (itv < 0) continue;
+    auto f = type_by_name.find(V.vals[ctx->kInstanceType].strs[itv]);
+    if (f == type_by_name.end()) continue;
+    ci.type = f->second;
+    for (auto& o : cat->types[ci.type].offerings) {
+      if (zone >= 0 && (int)o.zone != zone) continue;
+      if (ctv >= 0 && (int)o.ct != ctv) continue;
+      if (zid >= 0 && o.zid >= 0 && o.zid != zid) continue;
+      if (!ci.ok || o.price < ci.price) { ci.price = o.price; ci.ok = true; }
+    }
+  }
+  KG_PROF("plan: end");
+  return Pp;
+}
+
+static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, kg_cluster* cluster, const kg_pods_desc* pending,
+                                const kg_nodepools_desc* nodepools, const kg_candidates_desc* cands, bool multi, kg_candidate_record* records,
+                                uint32_t cap_records, uint32_t* n_records, double* device_ms, ValidateOut* vout = nullptr) {
+  if (!ctx || !catalogs || n_catalogs == 0 || !cluster || !nodepools || !cands || !n_records || (!records && cap_records)) return KG_EINVAL;
+  CtxLock lk(ctx);
+  KG_GUARD_BEGIN
+  if (n_catalogs != 1) throw Unsupported("one catalog per solve on the device path");
+  kg_catalog* cat = catalogs[0];
+  const uint32_t n = cands->n_candidates;
+  const int shards = std::max(cands->n_shards, 1);
+  check(cands->shard >= 0 && cands->shard < shards, "shard index");
+  for (uint32_t i = 0; i < n; ++i) check(cands->candidates[i] >= 0 && cands->candidates[i] < (int)cluster->nodes.size(), "candidate node index");
+  *n_records = 0;
+  if (device_ms) *device_ms = 0;
+  HostProf prof_;
+  KG_PROF("cons: plan lookup");
+  // ---- the plan: found by the content of what it was built from, or built now
+  kg_cons_plan* PLp = nullptr;
+  std::unique_ptr<kg_cons_plan> one_off;
+  if (vout) {
+    one_off = build_cons_plan(ctx, cat, cluster, pending, nodepools, cands, multi, true);
+    PLp = one_off.get();
+  } else {
+    Hasher H;
+    H.u64(cat->uid); H.u64(cat->generation); H.u64(cat->tab_epoch); H.u64((uint64_t)(uintptr_t)cat->tab.dev.ptr); H.u64(ctx->V.resources.size());
+    H.u64(multi); H.u64(ctx->collect_stats); H.u64((uint64_t)nodepools->max_instance_types);
+    H.arr(cands->candidates, n);
+    H.pools(nodepools->pools); H.arr(nodepools->nodepools, nodepools->n_nodepools); H.u64(nodepools->well_known_labels.begin); H.u64(nodepools->well_known_labels.count);
+    if (pending) {
+      H.pools(pending->pools); H.arr(pending->pods, pending->n_pods); H.arr(pending->weighted_terms, pending->n_weighted_terms); H.arr(pending->spreads, pending->n_spreads);
+      H.arr(pending->affinity_terms, pending->n_affinity_terms); H.arr(pending->host_ports, pending->n_host_ports);
+    }
+    for (auto* p : cluster->plans) if (p->key == H.h && p->multi == multi) PLp = p;
+    if (PLp) ctx->stats.cons_plan_hits += 1;
+    else {
+      ctx->stats.cons_plans_built += 1;
+      if (cluster->plans.size() >= 4) {  // (single + multi of the current and of the previous candidate order)
+        size_t old = 0;
+        for (size_t i = 1; i < cluster->plans.size(); ++i) if (cluster->plans[i]->last_use < cluster->plans[old]->last_use) old = i;
+        delete cluster->plans[old];
+        cluster->plans.erase(cluster->plans.begin() + old);
+      }
+      auto np = build_cons_plan(ctx, cat, cluster, pending, nodepools, cands, multi, false);
+      np->key = H.h;
+      PLp = np.release();
+      cluster->plans.push_back(PLp);
+    }
+    PLp->last_use = ++cluster->plan_clock;
+  }
+  kg_cons_plan& PL = *PLp;
+  Compiled* C = PL.C.get();
+  const uint32_t n_used = PL.n_used;
+  const std::vector<ConsUnit>& units = PL.units;
+  const std::vector<CandInfo>& cinfo = PL.cinfo;
+  const int spot = PL.spot, od = PL.od;
+  if (vout) multi = true;
+
+  KG_PROF("cons: shard");
+  // ---- this shard's units (unit u belongs to shard (u - lo) mod n_shards = its index mod n_shards)
+  std::vector<uint32_t> mine;
+  for (size_t k = 0; k < units.size(); ++k) if (vout || (int)(k % (size_t)shards) == cands->shard) mine.push_back((uint32_t)k);
+  *n_records = (uint32_t)mine.size();
+  if (mine.size() > cap_records) return fail(ctx, KG_ENOMEM, "record buffer too small");
+  for (size_t k = 0; k < mine.size(); ++k) {
+    std::memset(&records[k], 0, sizeof(kg_candidate_record));
+    records[k].candidate = (int32_t)units[mine[k]].id;
+  }
+  if (!C) return KG_OK;  // (no unit of the mode has pods to reschedule)
+  if (PL.shard != cands->shard || PL.n_shards != shards || !PL.run.ptr) {
+    // state slots and launch tables of this shard's live units: built when the shard is first run, reused by every later round
+    PL.shard = cands->shard; PL.n_shards = shards;
+    PL.live.clear();
+    for (uint32_t k : mine) if (!units[k].skip) PL.live.push_back(k);
+    hal::dfree(PL.arena.ptr); hal::dfree(PL.run.ptr);
+    PL.arena = DeviceBuffer(); PL.run = DeviceBuffer();
+    if (!PL.live.empty()) {
+      const size_t stride = C->state_bytes, budget = (size_t)8 << 30, nl = PL.live.size();
+      PL.max_batch = std::max<size_t>(1, std::min<size_t>(nl, budget / stride > 1 ? budget / stride - 1 : 1));
+      PL.arena.bytes = (PL.max_batch + 1) * stride;
+      PL.arena.ptr = hal::dmalloc(PL.arena.bytes);
+      // KG_POISON=1 (tests): whatever a simulation reads of its slot beyond the initialised prefix must have been written by it
+      if (getenv("KG_POISON")) hal::dfill(PL.arena.ptr, 0xAB, PL.arena.bytes);
+      hal::h2d(PL.arena.ptr, C->state_image.data(), C->state_init_bytes);
+      std::vector<SimState> sims(nl);
+      for (size_t i = 0; i < nl; ++i) {
+        sims[i] = sim_at(*C, (uint8_t*)PL.arena.ptr + (i % PL.max_batch + 1) * stride);
+        sims[i].n_shared = PL.n_shared;
+        sims[i].pod_base = units[PL.live[i]].pod_lo;
+      }
+      Arena RA;
+      PL.o_sims = RA.add(sims); PL.o_unit = RA.add(PL.live); PL.o_nq = RA.reserve(nl * 4); PL.o_res = RA.reserve(nl * sizeof(SimResult));
+      PL.run.bytes = RA.bytes.size();
+      PL.run.ptr = hal::dmalloc(PL.run.bytes);
+      hal::h2d(PL.run.ptr, RA.bytes.data(), PL.run.bytes);
+    }
+  }
+  const std::vector<uint32_t>& live = PL.live;
+  if (live.empty()) return KG_OK;
+
+  KG_PROF("cons: kernels");
+  double ms_total = PL.ms_prepass, ms_init = 0, ms_sim = 0, ms_gather = 0;
+  const float ms_pre = PL.ms_prepass;
+  PL.ms_prepass = 0;  // (the prepass ran when the plan was built: charged to the first round only)
+  const size_t stride = C->state_bytes;
+  std::vector<SimResult> results(live.size());
+  auto tp = [&](size_t off) { return (uint8_t*)PL.tables.ptr + off; };
+  auto rp_ = [&](size_t off) { return (uint8_t*)PL.run.ptr + off; };
+  for (size_t b0 = 0; b0 < live.size(); b0 += PL.max_batch) {
+    const size_t nb = std::min(PL.max_batch, live.size() - b0);
     SimBatch B{};
-    B.arena = (uint8_t*)arena.ptr; B.stride = stride; B.o_queue = C->o_queue; B.o_excl = C->o_excl; B.o_remaining = C->o_remaining;
-    B.q_off = (const uint32_t*)pp(o_qoff); B.q_ent = (const uint4*)pp(o_qent); B.x_off = (const uint32_t*)pp(o_xoff); B.x_node = (const uint32_t*)pp(o_xnode);
-    B.rem_adj = any_limits ? (const int64_t*)pp(o_rem) : nullptr; B.nqueue = (uint32_t*)pp(o_nq); B.results = (SimResult*)pp(o_res);
-    B.t_off = C->G > 0 ? (const uint32_t*)pp(o_toff) : nullptr; B.t_ent = (const uint32_t*)pp(o_tent); B.gdom_univ = (const uint64_t*)pp(o_guniv);
+    B.arena = (uint8_t*)PL.arena.ptr; B.stride = stride; B.init_bytes = C->state_init_bytes; B.o_queue = C->o_queue; B.o_excl = C->o_excl; B.o_remaining = C->o_remaining;
+    B.unit_of_sim = (const uint32_t*)rp_(PL.o_unit) + b0;
+    B.q_off = (const uint32_t*)tp(PL.o_qoff); B.q_ent = (const uint4*)tp(PL.o_qent); B.x_off = (const uint32_t*)tp(PL.o_xoff); B.x_node = (const uint32_t*)tp(PL.o_xnode);
+    B.rem_adj = PL.any_limits ? (const int64_t*)tp(PL.o_rem) : nullptr; B.nqueue = (uint32_t*)rp_(PL.o_nq) + b0; B.results = (SimResult*)rp_(PL.o_res) + b0;
+    B.t_off = C->G > 0 ? (const uint32_t*)tp(PL.o_toff) : nullptr; B.t_ent = (const uint32_t*)tp(PL.o_tent); B.gdom_univ = (const uint64_t*)tp(PL.o_guniv);
     B.o_gcount = C->o_gcount; B.o_gdom = C->o_gdom; B.o_gpos = C->o_gpos; B.o_hcount = C->o_hcount; B.o_hpos = C->o_hpos;
-    B.pod_nonpending = (const uint8_t*)pp(o_np); B.node_uninit = (const uint64_t*)pp(o_un); B.nsims = (int)nb;
+    B.pod_nonpending = (const uint8_t*)tp(PL.o_np); B.node_uninit = (const uint64_t*)tp(PL.o_un); B.nsims = (int)nb;
+    const SimState* sims_dev = (const SimState*)rp_(PL.o_sims) + b0;
     float ms_i = 0, ms_s = 0, ms_g = 0;
     hal::launch_sim_init(C->dp, B, &ms_i);
-    hal::launch_solve(C->dp, (const SimState*)pp(o_sims), (int)nb, B.nqueue, ctx->sim_block_threads, &ms_s, true);
-    hal::launch_sim_gather(C->dp, B, (const SimState*)pp(o_sims), &ms_g);
-    hal::d2h(results.data() + b0, pp(o_res), nb * sizeof(SimResult));
+    hal::launch_solve(C->dp, sims_dev, (int)nb, B.nqueue, ctx->sim_block_threads, &ms_s, true);
+    hal::launch_sim_gather(C->dp, B, sims_dev, &ms_g);
     ms_total += ms_i + ms_s + ms_g;
     ms_init += ms_i; ms_sim += ms_s; ms_gather += ms_g;
     ctx->stats.kernel_launches += 3;
     ctx->stats.solves += nb;
   }
+  hal::d2h(results.data(), rp_(PL.o_res), live.size() * sizeof(SimResult));
   if (device_ms) *device_ms = ms_total;
   ctx->stats.device_ms_total += ms_total;
   {
@@ -2220,39 +2405,14 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   }
   KG_PROF("cons: decisions");
   // ---- computeConsolidation's decision logic per simulation (prices are float64 catalog data: host side)
-  // capacity types in the catalog's value numbering (ctmask bits, CatOffering::lct); gspot: the context id node labels carry
-  const int gspot = V.vals[ctx->kCT].find("spot"), god = V.vals[ctx->kCT].find("on-demand");
-  const int spot = gspot < 0 ? -1 : cat->tab.local(ctx->kCT, (uint32_t)gspot), od = god < 0 ? -1 : cat->tab.local(ctx->kCT, (uint32_t)god);
-  std::unordered_map<std::string, int> type_by_name;
-  for (size_t t = 0; t < cat->types.size(); ++t) type_by_name.emplace(cat->types[t].name, (int)t);
-  std::vector<CandInfo> cinfo(n_used);
-  for (uint32_t i = 0; i < n_used; ++i) {
-    const CNode& nd = cluster->nodes[cands->candidates[i]];
-    int zone = -1, ctv = -1, zid = -1, itv = -1;
-    for (auto& kv : nd.labels) {
-      if (kv.first == ctx->kZone) zone = (int)kv.second;
-      if (kv.first == ctx->kCT) ctv = (int)kv.second;
-      if (kv.first == ctx->kZid) zid = (int)kv.second;
-      if (kv.first == ctx->kInstanceType) itv = (int)kv.second;
-    }
-    CandInfo& ci = cinfo[i];
-    ci.spot = ctv >= 0 && ctv == gspot;
-    if (itv < 0) continue;
-    auto f = type_by_name.find(V.vals[ctx->kInstanceType].strs[itv]);
-    if (f == type_by_name.end()) continue;
-    ci.type = f->second;
-    for (auto& o : cat->types[ci.type].offerings) {
-      if (zone >= 0 && (int)o.zone != zone) continue;
-      if (ctv >= 0 && (int)o.ct != ctv) continue;
-      if (zid >= 0 && o.zid >= 0 && o.zid != zid) continue;
-      if (!ci.ok || o.price < ci.price) { ci.price = o.price; ci.ok = true; }
-    }
-  }
+  // (records[] is indexed by position in `mine`; live[li] is a unit index)
+  std::vector<uint32_t> rec_of_unit(units.size(), 0);
+  for (size_t k = 0; k < mine.size(); ++k) rec_of_unit[mine[k]] = (uint32_t)k;
   const uint8_t* zone_zid = cat->tab.image.bytes.data() + cat->tab.o_zone_zid;
   for (size_t li = 0; li < live.size(); ++li) {
-    const Unit& un = units[live[li]];
+    const ConsUnit& un = units[live[li]];
     const SimResult& sr = results[li];
-    kg_candidate_record& rec = records[live[li]];
+    kg_candidate_record& rec = records[rec_of_unit[live[li]]];
     Replacement rp;
     const uint32_t c0 = multi ? 0 : un.id, c1 = un.id + 1;
     if (sr.errors == 0 && sr.nclaims == 0) rp.decision = KG_DECISION_DELETE;

@@ -179,6 +179,10 @@ struct DevProblem {
   const uint8_t* zone_zid;      // [64] zone value id -> zone-id value id, 0xFF none
   int n_zone_vals, n_ct_vals;
   // existing nodes (scan order)
+  uint32_t sparse_nodes;        // batches of simulations: a simulation keeps what it adds to existing nodes as a short list of
+                                // touched nodes (SimState::tnode ...) over the shared nreq0 / nports0 instead of its own [R][N] copy
+  const int64_t* nreq0;         // [R][N] requests already on the node before this Solve (remaining daemonset requests)
+  const uint64_t* nports0;      // [N] host-port ids reserved on the node by its bound pods
   const int64_t* navail;        // [R][N]
   const uint64_t* nlab;         // [S][NW] label compat per requirement set (k_node_static)
   const uint64_t* ntol;         // [TS][NW]
@@ -190,8 +194,13 @@ struct DevProblem {
 
 // Mutable state of ONE simulation (device pointers into that simulation's arena).
 struct SimState {
-  KG_GLOBAL int64_t* nreq;      // [R][N]
+  KG_GLOBAL int64_t* nreq;      // [R][N] (dense mode: one Solve)
   KG_GLOBAL uint64_t* nports;   // [N] host-port ids reserved on the node (bit per entry of the solve's port vocabulary)
+  // sparse mode (DevProblem::sparse_nodes): nodes this simulation has put pods on -- header[6] entries
+  KG_GLOBAL uint64_t* ntouch;   // [NW] bit per node: it has an entry below
+  KG_GLOBAL uint32_t* tnode;    // [Cmax] node (scan position)
+  KG_GLOBAL int64_t* tadd;      // [R][Cmax] requests this simulation added to it
+  KG_GLOBAL uint64_t* tports;   // [Cmax] its host-port word now
   KG_GLOBAL uint64_t* c_ports;  // [Cmax] ... on the NodeClaim
   KG_GLOBAL uint64_t* c_row;    // [Cmax][112] claim rows of the single-wave solve (solve_wave.hpp); device-only scratch behind the state image
   KG_GLOBAL int64_t* c_req;     // [R][Cmax]
@@ -761,10 +770,25 @@ KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, c
   const uint32_t wi = n >> 6, bi = n & 63;
   if ((S.excl[wi] >> bi) & 1) return false;  // a candidate of this simulation: not a state node
   if (!((P.ntol[(size_t)v.tolset * P.NW + wi] >> bi) & 1)) { *reason |= 1; return false; }
-  if (P.has_ports && (S.nports[n] & pc.vc.hp_conf)) { *reason |= 2; return false; }  // HostPortUsage.Conflicts
-  // resources first (cheap reject), as upstream does
-  for (int r = 0; r < P.R; ++r) {
-    if (pc.preq[r] != 0 && S.nreq[(size_t)r * P.N + n] + pc.preq[r] > P.navail[(size_t)r * P.N + n]) { *reason |= 64; return false; }
+  int tk = -1;  // sparse mode: the node's entry in the simulation's touched list
+  if (P.sparse_nodes) {
+    if ((S.ntouch[wi] >> bi) & 1) {
+      const uint32_t nt = S.header[6];
+      for (uint32_t k = 0; k < nt; ++k) if (S.tnode[k] == n) { tk = (int)k; break; }
+    }
+    if (P.has_ports && ((tk >= 0 ? S.tports[tk] : P.nports0[n]) & pc.vc.hp_conf)) { *reason |= 2; return false; }  // HostPortUsage.Conflicts
+    // resources first (cheap reject), as upstream does
+    for (int r = 0; r < P.R; ++r) {
+      if (pc.preq[r] == 0) continue;
+      const int64_t have = P.nreq0[(size_t)r * P.N + n] + (tk >= 0 ? S.tadd[(size_t)r * P.Cmax + tk] : 0);
+      if (have + pc.preq[r] > P.navail[(size_t)r * P.N + n]) { *reason |= 64; return false; }
+    }
+  } else {
+    if (P.has_ports && (S.nports[n] & pc.vc.hp_conf)) { *reason |= 2; return false; }  // HostPortUsage.Conflicts
+    // resources first (cheap reject), as upstream does
+    for (int r = 0; r < P.R; ++r) {
+      if (pc.preq[r] != 0 && S.nreq[(size_t)r * P.N + n] + pc.preq[r] > P.navail[(size_t)r * P.N + n]) { *reason |= 64; return false; }
+    }
   }
   if (!((P.nlab[(size_t)v.rs * P.NW + wi] >> bi) & 1)) { *reason |= 2; return false; }
   for (uint32_t li = 0; li < pc.vc.nlist; ++li) {
@@ -782,8 +806,21 @@ KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, c
     if (!o.ok || !((o.opts >> d) & 1)) { *reason |= 4; return false; }
   }
   if (COMMIT) {
-    for (int r = 0; r < P.R; ++r) if (pc.preq[r] != 0) S.nreq[(size_t)r * P.N + n] += pc.preq[r];
-    if (P.has_ports) S.nports[n] |= pc.vc.hp_use;
+    if (P.sparse_nodes) {
+      if (tk < 0) {  // (one thread commits: the list grows by at most one entry per placed pod, Cmax in all)
+        tk = (int)S.header[6];
+        S.header[6] = (uint32_t)tk + 1;
+        S.tnode[tk] = n;
+        for (int r = 0; r < P.R; ++r) S.tadd[(size_t)r * P.Cmax + tk] = 0;
+        S.tports[tk] = P.has_ports ? P.nports0[n] : 0;
+        S.ntouch[wi] |= 1ull << bi;
+      }
+      for (int r = 0; r < P.R; ++r) if (pc.preq[r] != 0) S.tadd[(size_t)r * P.Cmax + tk] += pc.preq[r];
+      if (P.has_ports) S.tports[tk] |= pc.vc.hp_use;
+    } else {
+      for (int r = 0; r < P.R; ++r) if (pc.preq[r] != 0) S.nreq[(size_t)r * P.N + n] += pc.preq[r];
+      if (P.has_ports) S.nports[n] |= pc.vc.hp_use;
+    }
     for (uint32_t li = 0; li < v.record_cnt; ++li) {
       const ListEntry le = P.lists[v.record_off + li];
       const Group g = P.groups[le.g];
@@ -1753,9 +1790,11 @@ struct SimResult {
 
 struct SimBatch {
   uint8_t* arena;            // (nsims + 1) slots of `stride` bytes; slot 0 holds the pristine state image
-  unsigned long long stride;
+  unsigned long long stride;      // bytes per slot
+  unsigned long long init_bytes;  // ... of which the pristine image initialises this prefix (the rest is written before it is read)
   unsigned long long o_queue, o_excl, o_remaining;
-  const uint32_t* q_off;     // [nsims + 1] -> q_ent
+  const uint32_t* unit_of_sim; // [nsims] the unit (row of the per-unit tables below) simulation i runs
+  const uint32_t* q_off;     // [units + 1] -> q_ent
   const uint4* q_ent;        // initial queue entries {pod, variant, 0, 0} of every simulation, each in Queue order
   const uint32_t* x_off;     // [nsims + 1] -> x_node
   const uint32_t* x_node;    // scan positions of the candidate nodes of every simulation
@@ -1775,20 +1814,21 @@ struct SimBatch {
 KG_HD void sim_init_copy(const SimBatch& B, uint32_t i, uint32_t tid, uint32_t nthreads) {
   const uint64_t* src = (const uint64_t*)B.arena;
   uint64_t* dst = (uint64_t*)(B.arena + (size_t)(i + 1) * B.stride);
-  for (size_t k = tid; k < B.stride / 8; k += nthreads) dst[k] = src[k];
+  for (size_t k = tid; k < B.init_bytes / 8; k += nthreads) dst[k] = src[k];
 }
 KG_HD void sim_init_patch(const DevProblem& P, const SimBatch& B, uint32_t i, uint32_t tid, uint32_t nthreads) {
   uint8_t* slot = B.arena + (size_t)(i + 1) * B.stride;
   uint4* q = (uint4*)(slot + B.o_queue);
-  const uint32_t q0 = B.q_off[i], qn = B.q_off[i + 1] - q0;
+  const uint32_t u = B.unit_of_sim[i];
+  const uint32_t q0 = B.q_off[u], qn = B.q_off[u + 1] - q0;
   for (uint32_t k = tid; k < qn; k += nthreads) q[k] = B.q_ent[q0 + k];
   if (tid == 0) {
     B.nqueue[i] = qn;
     uint64_t* excl = (uint64_t*)(slot + B.o_excl);
-    for (uint32_t k = B.x_off[i]; k < B.x_off[i + 1]; ++k) excl[B.x_node[k] >> 6] |= 1ull << (B.x_node[k] & 63);
+    for (uint32_t k = B.x_off[u]; k < B.x_off[u + 1]; ++k) excl[B.x_node[k] >> 6] |= 1ull << (B.x_node[k] & 63);
     if (B.rem_adj) {
       int64_t* rem = (int64_t*)(slot + B.o_remaining);
-      for (int k = 0; k < P.R * P.NP; ++k) if (rem[k] != 0x7FFFFFFFFFFFFFFFll) rem[k] += B.rem_adj[(size_t)i * P.R * P.NP + k];
+      for (int k = 0; k < P.R * P.NP; ++k) if (rem[k] != 0x7FFFFFFFFFFFFFFFll) rem[k] += B.rem_adj[(size_t)u * P.R * P.NP + k];
     }
     if (B.t_off) {
       // Topology.excludedPods: the pods this simulation reschedules do not count in the initial domains
@@ -1797,7 +1837,7 @@ KG_HD void sim_init_patch(const DevProblem& P, const SimBatch& B, uint32_t i, ui
       uint64_t* gpos = (uint64_t*)(slot + B.o_gpos);
       int32_t* hc = (int32_t*)(slot + B.o_hcount);
       int32_t* hpos = (int32_t*)(slot + B.o_hpos);
-      for (uint32_t k = B.t_off[i]; k < B.t_off[i + 1]; ++k) {
+      for (uint32_t k = B.t_off[u]; k < B.t_off[u + 1]; ++k) {
         const uint32_t e = B.t_ent[k];
         if (e >> 31) {
           const uint32_t idx = e & 0x7FFFFFFFu;
@@ -1818,7 +1858,8 @@ KG_HD void sim_gather(const DevProblem& P, const SimBatch& B, const SimState& S,
   r.nclaims = S.header[0];
   r.errors = 0;
   uint32_t claim0_np = 0;
-  for (uint32_t k = B.q_off[i]; k < B.q_off[i + 1]; ++k) {
+  const uint32_t u = B.unit_of_sim[i];
+  for (uint32_t k = B.q_off[u]; k < B.q_off[u + 1]; ++k) {
     const uint32_t pod = B.q_ent[k].x;
     if (!B.pod_nonpending[pod]) continue;
     const uint32_t row = pod_row(S, pod);

@@ -255,3 +255,84 @@ def check_multi_over_100(L, n=140):
     finally:
         L.dll.kg_cluster_free(hcl)
         L.dll.kg_catalog_free(hcat)
+
+
+def check_plan_reuse(L, name="dense", n=90):
+    """Rounds over one snapshot reuse what the first prepared (kg_stats.cons_plan_hits) and still give the oracle's records:
+    the same round again, the shards of a 3-way split in turn (twice), single / multi alternating; and whatever the plan
+    was built from changing -- an in-place catalog update, another candidate order, other pending pods, the visit-counter
+    setting -- prepares anew.  More plans than a snapshot keeps (4) evict the least recently used one."""
+    from tests.update_common import apply_updates
+    types, nodes, bound, _ = cluster(name, n)
+    zones, _t = catalog776()
+    order = wl.disruption_order(nodes, bound)
+    cat, cl = abi.build_catalog(types), abi.build_cluster(nodes, bound)
+    pend, nps = abi.build_pods([]), abi.build_nodepools([wl.default_nodepool()], wl.WELL_KNOWN_LABELS)
+    hcat, hcl = L.catalog_upload(cat), L.cluster_upload(cl)
+    tup = lambda recs: [abi.record_tuple(r) for r in recs]
+
+    def oracle(cat_, pend_, cd, multi):
+        st, ro, _ = loader.consolidate_records([cat_], cl, pend_, nps, cd, multi)
+        assert st == 0
+        return tup(ro)
+
+    def counters():
+        s = L.stats()
+        return int(s.cons_plans_built), int(s.cons_plan_hits)
+
+    try:
+        cd = abi.build_candidates(order, spot_to_spot=True)
+        want = {m: oracle(cat, pend, cd, m) for m in (False, True)}
+        b0, h0 = counters()
+        for rnd in range(3):
+            for multi in (False, True):
+                assert tup(L.consolidate_records([hcat], hcl, pend, nps, cd, multi)[0]) == want[multi], (rnd, multi)
+        assert counters() == (b0 + 2, h0 + 4)
+        for rnd in range(2):  # the shards of a 3-way split share the plan; their records interleave to the whole
+            parts = [tup(L.consolidate_records([hcat], hcl, pend, nps, abi.build_candidates(order, spot_to_spot=True, shard=s, n_shards=3), False)[0]) for s in range(3)]
+            assert sorted(sum(parts, []), key=lambda r: r[0]) == want[False]
+        assert counters() == (b0 + 2, h0 + 10)
+        # spot-to-spot is decided per call on the cached simulations
+        cd_off = abi.build_candidates(order, spot_to_spot=False)
+        assert tup(L.consolidate_records([hcat], hcl, pend, nps, cd_off, False)[0]) == oracle(cat, pend, cd_off, False)
+        assert counters() == (b0 + 2, h0 + 11)
+        # an in-place catalog update: the c / m / r families of generations 5 and 6 sold out everywhere, t3 spot nearly free
+        ups = []
+        for i, t in enumerate(types):
+            fam = t["name"].split(".")[0]
+            if fam[0] in "cmr" and fam[1] in "56":
+                ups += [(i, z, ct, False, None) for z in zones for ct in ("spot", "on-demand") if any(o[0] == z and o[1] == ct for o in t["offerings"])]
+            if fam == "t3":
+                ups += [(i, z, "spot", None, 0.0003) for z in zones if any(o[0] == z and o[1] == "spot" for o in t["offerings"])]
+        types_b = apply_updates(types, ups)
+        L.catalog_update_offerings(hcat, ups, generation=2)
+        cat_b = abi.build_catalog(types_b)
+        want_b = oracle(cat_b, pend, cd, False)
+        assert want_b != want[False] or name != "dense"
+        assert tup(L.consolidate_records([hcat], hcl, pend, nps, cd, False)[0]) == want_b
+        assert counters() == (b0 + 3, h0 + 11)
+        # another candidate order, other pending pods, the production setting (prefilter path)
+        rev = abi.build_candidates(order[::-1], spot_to_spot=True)
+        assert tup(L.consolidate_records([hcat], hcl, pend, nps, rev, False)[0]) == oracle(cat_b, pend, rev, False)
+        pend2 = abi.build_pods(wl.mixed_pods(5, 4, zones, families(types)))
+        assert tup(L.consolidate_records([hcat], hcl, pend2, nps, cd, False)[0]) == oracle(cat_b, pend2, cd, False)
+        L.set_collect_stats(False)
+        try:
+            assert tup(L.consolidate_records([hcat], hcl, pend, nps, cd, False)[0]) == want_b
+            assert tup(L.consolidate_records([hcat], hcl, pend, nps, cd, True)[0]) == oracle(cat_b, pend, cd, True)
+        finally:
+            L.set_collect_stats(True)
+        assert counters() == (b0 + 7, h0 + 11)
+        # (7 plans built over a snapshot that keeps 4) the evicted first ones are prepared again, the kept ones are found
+        assert tup(L.consolidate_records([hcat], hcl, pend2, nps, cd, False)[0]) == oracle(cat_b, pend2, cd, False)
+        assert counters() == (b0 + 7, h0 + 12)
+        assert tup(L.consolidate_records([hcat], hcl, pend, nps, cd, False)[0]) == want_b
+        assert counters()[0] == b0 + 8
+        # a validated command does not disturb the plans
+        rec = [r for r in L.consolidate_records([hcat], hcl, pend, nps, cd, False)[0] if int(r["decision"]) == 1]
+        if rec:
+            assert L.consolidate_validate([hcat], hcl, pend, nps, [order[int(rec[0]["candidate"])]], 1, [])
+        assert tup(L.consolidate_records([hcat], hcl, pend, nps, cd, False)[0]) == want_b
+    finally:
+        L.dll.kg_cluster_free(hcl)
+        L.dll.kg_catalog_free(hcat)

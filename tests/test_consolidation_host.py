@@ -38,3 +38,9 @@ def test_validate_command(L):
 def test_multi_node_more_than_100_candidates(L):
     from tests.cons_common import check_multi_over_100
     check_multi_over_100(L)
+
+
+@pytest.mark.parametrize("name", ["dense", "topology"])
+def test_rounds_reuse_the_prepared_snapshot(L, name):
+    from tests.cons_common import check_plan_reuse
+    check_plan_reuse(L, name)
