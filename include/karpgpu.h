@@ -288,6 +288,8 @@ typedef struct {
   uint8_t has_gt, has_lt;
   int64_t gt, lt;
   kg_range values;          /* into value_ids[] */
+  int32_t min_values;       /* NodeSelectorRequirementWithMinValues.MinValues the claim carries for the key; -1 = none */
+  uint32_t pad_;
 } kg_req_out;
 
 /* All arrays are caller-allocated; cap_* are capacities, n_* are filled by the library and
@@ -462,6 +464,24 @@ int32_t kg_truncate(kg_ctx* ctx, kg_catalog* catalog, const kg_pools* pools, kg_
 int32_t kg_launch_filter(kg_ctx* ctx, kg_catalog* catalog, const kg_pools* pools, kg_range requirements,
                          kg_range requests, int32_t max_types,
                          uint32_t* out_type_ids, uint32_t cap, uint32_t* n_out, uint8_t* min_values_failed);
+
+/* getCapacityType + getOverrides of a launch (pkg/providers/instance/instance.go:372-385, 323-359), the step between the
+ * launch filter and CreateFleet.  *capacity_type = KG_CT_SPOT when the requirements admit spot and one of the given types has
+ * an available offering compatible with them once capacity-type is pinned to spot, else KG_CT_ON_DEMAND.  out[] receives the
+ * override list: for every type in type_ids order, every AVAILABLE offering in the type's offering order that is compatible
+ * with the requirements (capacity-type replaced by the chosen one) and whose zone has a subnet -- subnet_zones are the keys
+ * of ZonalSubnetsForLaunch (string ids into pools->strings); kg_override.subnet = index into subnet_zones, from which the
+ * caller fills SubnetId / AvailabilityZone.  *n_out = entries the launch has (0: "no capacity offerings are currently
+ * available given the constraints", instance.go:315-317); KG_ENOMEM when cap is smaller. */
+#define KG_CT_ON_DEMAND 0
+#define KG_CT_SPOT 1
+typedef struct {
+  uint32_t type_id;
+  uint32_t subnet;
+} kg_override;
+int32_t kg_launch_overrides(kg_ctx* ctx, kg_catalog* catalog, const kg_pools* pools, kg_range requirements,
+                            const uint32_t* type_ids, uint32_t n_types, const uint32_t* subnet_zones, uint32_t n_subnet_zones,
+                            int32_t* capacity_type, kg_override* out, uint32_t cap, uint32_t* n_out);
 
 /* consolidation: one independent SimulateScheduling per candidate (single) or per prefix (multi).
  * records[] receives one kg_candidate_record per unit evaluated by this shard (cap_records);

@@ -44,7 +44,7 @@ NODEPOOL = np.dtype([("name", "<u4"), ("weight", "<i4"), ("requirements", RANGE)
 CLAIM_OUT = np.dtype([("nodepool", "<u4"), ("n_pods", "<u4"), ("types", RANGE), ("requirements", RANGE), ("requests", RANGE),
                       ("truncation_failed", "u1")], align=True)
 REQ_OUT = np.dtype([("key", "<u4"), ("complement", "u1"), ("has_gt", "u1"), ("has_lt", "u1"), ("gt", "<i8"), ("lt", "<i8"),
-                    ("values", RANGE)], align=True)
+                    ("values", RANGE), ("min_values", "<i4"), ("pad_", "<u4")], align=True)
 CANDIDATE_RECORD = np.dtype([("candidate", "<i4"), ("decision", "<i4"), ("nodepool", "<u4"), ("n_types", "<u4"),
                              ("candidate_price", "<f8"), ("type_mask", "<u8", (16,)), ("zone_mask", "<u8"), ("ct_mask", "<u8"),
                              ("spot_only", "u1"), ("pad", "u1", (7,))], align=True)
@@ -424,6 +424,8 @@ class ResultBuffers:
                     vals = tuple(sorted(self.string(int(v)) for v in self.value_ids[vb:vb + vc]))
                     reqs[self.string(int(q["key"]))] = (bool(q["complement"]), vals,
                                                         int(q["gt"]) if q["has_gt"] else None, int(q["lt"]) if q["has_lt"] else None)
+                    if int(q["min_values"]) >= 0:
+                        claim.setdefault("min_values", {})[self.string(int(q["key"]))] = int(q["min_values"])
                 claim["requirements"] = reqs
             out["claims"].append(claim)
         return out
@@ -466,14 +468,21 @@ def record_tuple(r):
             tuple(int(x) for x in r["type_mask"]), int(r["spot_only"]))
 
 
-def build_launch(requirements, requests):
-    """A NodeClaim's launch inputs: (Pools, requirements range, requests range) for kg_launch_filter / kg_truncate."""
+def build_launch(requirements, requests, strings=()):
+    """A NodeClaim's launch inputs: (Pools, requirements range, requests range) for kg_launch_filter / kg_truncate /
+    kg_launch_overrides; with `strings`, their ids in the pools' string table come back as a fourth element."""
     pb = _PoolBuilder()
     pb.s("nodeclaim")
     rr = pb.req_list(requirements)
     qq = pb.quantity_list(requests)
+    ids = [pb.s(s) for s in strings]
     pools = pb.finish()
+    if strings:
+        return Built(pools, [pb]), Range(*rr), Range(*qq), ids
     return Built(pools, [pb]), Range(*rr), Range(*qq)
+
+
+OVERRIDE = np.dtype([("type_id", "<u4"), ("subnet", "<u4")])
 
 
 AMI_FAMILIES = {"AL2": 0, "AL2023": 1, "Bottlerocket": 2, "Ubuntu": 3, "Windows2019": 4, "Windows2022": 5, "Custom": 6}

@@ -1881,6 +1881,8 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
       q.key = W.add_string(V.keys.strs[r.key]);
       q.complement = r.compl_;
       q.has_gt = r.has_gt; q.has_lt = r.has_lt; q.gt = r.gt; q.lt = r.lt;
+      q.min_values = -1;  // (pods carry none: a claim's minValues are its NodePool's)
+      for (auto& t : tp.reqs.rs) if (t.key == r.key) q.min_values = t.min_values;
       std::vector<std::string> vs;
       for (uint32_t v : r.vals) vs.push_back(V.vals[r.key].strs[v]);
       std::sort(vs.begin(), vs.end());
@@ -2744,6 +2746,52 @@ int32_t kg_launch_filter(kg_ctx* ctx, kg_catalog* catalog, const kg_pools* pools
   *n_out = (uint32_t)cv.types.size();
   for (size_t i = 0; i < cv.types.size() && i < cap; ++i) out_type_ids[i] = cv.types[i];
   return cv.types.size() > cap ? fail(ctx, KG_ENOMEM, "type id buffer too small") : KG_OK;
+  KG_GUARD_END(ctx)
+}
+
+// getCapacityType (instance.go:372-385) + getOverrides (instance.go:323-359).  An offering's requirements are its zone,
+// capacity type and (when the zone has one) zone id, all well-known labels: Compatible(..., AllowUndefinedWellKnownLabels)
+// reduces to "the NodeClaim's requirement on each of the three keys, if it has one, admits the offering's value" -- the
+// zone / capacity-type masks launch_view derives (zone id folded into the zone mask).
+int32_t kg_launch_overrides(kg_ctx* ctx, kg_catalog* catalog, const kg_pools* pools, kg_range requirements, const uint32_t* type_ids, uint32_t n_types,
+                            const uint32_t* subnet_zones, uint32_t n_subnet_zones, int32_t* capacity_type, kg_override* out, uint32_t cap, uint32_t* n_out) {
+  if (!ctx || !catalog || !pools || (!type_ids && n_types) || (!subnet_zones && n_subnet_zones) || !capacity_type || !n_out || (!out && cap)) return KG_EINVAL;
+  CtxLock lk(ctx);
+  KG_GUARD_BEGIN
+  Vocab& V = ctx->V;
+  HReqs reqs = parse_reqs(V, *pools, requirements);
+  ClaimView cv;
+  launch_view(ctx, catalog, reqs, &cv);
+  for (uint32_t i = 0; i < n_types; ++i) check(type_ids[i] < catalog->types.size(), "type id");
+  const int gspot = V.vals[ctx->kCT].find("spot"), god = V.vals[ctx->kCT].find("on-demand");
+  const int spot = gspot < 0 ? -1 : catalog->tab.local(ctx->kCT, (uint32_t)gspot), od = god < 0 ? -1 : catalog->tab.local(ctx->kCT, (uint32_t)god);
+  // requirements.Get(capacity-type).Has("spot"): a NodeClaim without the key admits everything (Exists)
+  const HReq* ctr = reqs.find(ctx->kCT);
+  const bool spot_ok = !ctr || (gspot >= 0 ? ctr->has(V, (uint32_t)gspot) : ctr->has(V, V.val(ctx->kCT, "spot")));
+  int ct = od;
+  *capacity_type = KG_CT_ON_DEMAND;
+  if (spot_ok && spot >= 0)
+    for (uint32_t i = 0; i < n_types && ct == od; ++i)
+      for (auto& o : catalog->types[type_ids[i]].offerings)
+        if (o.available && (int)o.lct == spot && ((cv.zmask >> o.lz) & 1)) { ct = spot; *capacity_type = KG_CT_SPOT; break; }
+  // zone -> first subnet entry naming it (catalog-local zone numbering; a zone the catalog has never listed matches nothing)
+  int subnet_of_zone[64];
+  for (int z = 0; z < 64; ++z) subnet_of_zone[z] = -1;
+  for (uint32_t s = 0; s < n_subnet_zones; ++s) {
+    const int g = V.vals[ctx->kZone].find(std::string(kgdesc::str(pools->strings, subnet_zones[s])));
+    const int l = g < 0 ? -1 : catalog->tab.local(ctx->kZone, (uint32_t)g);
+    if (l >= 0 && l < 64 && subnet_of_zone[l] < 0) subnet_of_zone[l] = (int)s;
+  }
+  uint32_t n = 0;
+  if (ct >= 0)
+    for (uint32_t i = 0; i < n_types; ++i)
+      for (auto& o : catalog->types[type_ids[i]].offerings) {
+        if (!o.available || (int)o.lct != ct || !((cv.zmask >> o.lz) & 1) || subnet_of_zone[o.lz] < 0) continue;
+        if (n < cap) out[n] = kg_override{type_ids[i], (uint32_t)subnet_of_zone[o.lz]};
+        n++;
+      }
+  *n_out = n;
+  return n > cap ? fail(ctx, KG_ENOMEM, "override buffer too small") : KG_OK;
   KG_GUARD_END(ctx)
 }
 

@@ -14,7 +14,7 @@ DEFAULT_PATH = os.path.join(_HERE, "libkarpgpu.so")
 
 EXPORTS = ["kg_init", "kg_destroy", "kg_last_error", "kg_stats_get", "kg_catalog_upload", "kg_catalog_build_ec2", "kg_catalog_update_offerings", "kg_candidates_order", "kg_consolidate_validate",
            "kg_catalog_query", "kg_catalog_size", "kg_catalog_free", "kg_cluster_upload", "kg_cluster_free", "kg_solve",
-           "kg_truncate", "kg_launch_filter", "kg_consolidate_single", "kg_consolidate_multi", "kg_consolidate_select", "kg_solve_noalloc", "kg_catalog_query_requirements"]
+           "kg_truncate", "kg_launch_filter", "kg_consolidate_single", "kg_consolidate_multi", "kg_consolidate_select", "kg_solve_noalloc", "kg_catalog_query_requirements", "kg_launch_overrides"]
 
 
 class KgError(RuntimeError):
@@ -49,6 +49,8 @@ class Library:
                            C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
         d.kg_launch_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, abi.Range, abi.Range, C.c_int32, C.c_void_p, C.c_uint32,
                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
+        d.kg_launch_overrides.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, abi.Range, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                          C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         d.kg_truncate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, abi.Range, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p,
                                   C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
         d.kg_consolidate_select.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -191,6 +193,18 @@ class Library:
         self._check(self.dll.kg_launch_filter(self.ctx, catalog, C.addressof(pools.desc), rr, qq, max_types, out.ctypes.data, out.shape[0],
                                               C.byref(n), C.byref(mv)))
         return out[:n.value].tolist(), bool(mv.value)
+
+    def launch_overrides(self, catalog, requirements, type_ids, subnet_zones):
+        """getCapacityType + getOverrides -> ("spot" | "on-demand", [(type id, zone)])."""
+        import numpy as np
+        zones = list(subnet_zones)
+        pools, rr, _, zid = abi.build_launch(requirements, {}, zones or ["-"])
+        ids, zs = np.array(list(type_ids), dtype="<u4"), np.array(zid[:len(zones)], dtype="<u4")
+        out = np.zeros(max(len(ids), 1) * max(len(zones), 1) * 2, abi.OVERRIDE)
+        n, ct = C.c_uint32(0), C.c_int32(-1)
+        self._check(self.dll.kg_launch_overrides(self.ctx, catalog, C.addressof(pools.desc), rr, ids.ctypes.data if len(ids) else None, len(ids),
+                                                 zs.ctypes.data if len(zs) else None, len(zs), C.byref(ct), out.ctypes.data, out.shape[0], C.byref(n)))
+        return ("spot" if ct.value == 1 else "on-demand"), [(int(o["type_id"]), zones[int(o["subnet"])]) for o in out[:n.value]]
 
     def truncate(self, catalog, requirements, type_ids, max_types=60):
         import numpy as np

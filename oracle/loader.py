@@ -28,6 +28,9 @@ def lib():
         _LIB.ko_consolidate_records.restype = C.c_int32
         _LIB.ko_consolidate_records.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                                 C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+        _LIB.ko_launch_overrides.restype = C.c_int32
+        _LIB.ko_launch_overrides.argtypes = [C.c_void_p, C.c_void_p, abi.Range, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                             C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         _LIB.ko_launch_filter.restype = C.c_int32
         _LIB.ko_launch_filter.argtypes = [C.c_void_p, C.c_void_p, abi.Range, abi.Range, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                           C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
@@ -114,6 +117,20 @@ def launch_filter(catalog, requirements, requests, well_known, max_types=60):
                                 out.shape[0], C.byref(n), C.byref(mv))
     assert st == 0
     return out[:n.value].tolist(), bool(mv.value)
+
+
+def launch_overrides(catalog, requirements, type_ids, subnet_zones, well_known):
+    import numpy as np
+    zones = list(subnet_zones)
+    pools, rr, _, zid = abi.build_launch(requirements, {}, zones or ["-"])
+    ids, zs = np.array(list(type_ids), dtype="<u4"), np.array(zid[:len(zones)], dtype="<u4")
+    wk = (C.c_char_p * len(well_known))(*[w.encode() for w in well_known])
+    out = np.zeros(max(len(ids), 1) * max(len(zones), 1) * 2, abi.OVERRIDE)
+    n, ct = C.c_uint32(0), C.c_int32(-1)
+    st = lib().ko_launch_overrides(C.addressof(catalog.desc), C.addressof(pools.desc), rr, ids.ctypes.data if len(ids) else None, len(ids),
+                                   zs.ctypes.data if len(zs) else None, len(zs), wk, len(well_known), C.byref(ct), out.ctypes.data, out.shape[0], C.byref(n))
+    assert st == 0
+    return ("spot" if ct.value == 1 else "on-demand"), [(int(o["type_id"]), zones[int(o["subnet"])]) for o in out[:n.value]]
 
 
 def truncate(catalog, requirements, type_ids, max_types=60):

@@ -1243,6 +1243,7 @@ static void writeReqs(kgdesc::ResultWriter& W, const Requirements& reqs, kg_rang
     q.has_lt = r.lt.has_value();
     q.gt = r.gt.value_or(0);
     q.lt = r.lt.value_or(0);
+    q.min_values = r.minValues.value_or(-1);
     q.values.begin = W.r->needed_value_ids;
     q.values.count = 0;
     for (int v : r.SortedValues()) { W.add_value(W.add_string(G->s(v))); q.values.count++; }
@@ -1762,6 +1763,58 @@ int32_t ko_launch_filter(const kg_catalog_desc* catalog, const kg_pools* pools, 
     return KG_OK;
   } catch (const std::exception& e) {
     fprintf(stderr, "ko_launch_filter: %s\n", e.what());
+    return KG_EINVAL;
+  }
+}
+
+// getCapacityType + getOverrides (pkg/providers/instance/instance.go:372-385, 323-359): the capacity type CreateFleet is
+// asked for and the (instance type, zonal subnet) override list, types in the given order, offerings in catalog order.
+int32_t ko_launch_overrides(const kg_catalog_desc* catalog, const kg_pools* pools, kg_range requirements, const uint32_t* type_ids, uint32_t n_types,
+                            const uint32_t* subnet_zones, uint32_t n_subnet_zones, const char* const* well_known, uint32_t n_well_known,
+                            int32_t* capacity_type, kg_override* out, uint32_t cap, uint32_t* n_out) {
+  try {
+    Problem pr;
+    G = &pr.in;
+    SchedCtx& C = pr.C;
+    C.keyZone = pr.in.id("topology.kubernetes.io/zone"); C.keyCT = pr.in.id("karpenter.sh/capacity-type"); C.keyZoneID = pr.in.id("topology.k8s.aws/zone-id");
+    C.valSpot = pr.in.id("spot"); C.valOnDemand = pr.in.id("on-demand");
+    for (uint32_t i = 0; i < n_well_known; ++i) C.wellKnown.insert(pr.in.id(well_known[i]));
+    Parser P{pr.in};
+    auto cat = parseCatalog(pr.in, catalog, C.keyCT, C.keyZone, C.keyZoneID);
+    Requirements reqs = P.reqs(*pools, requirements);
+    vector<InstanceType*> its;
+    for (uint32_t i = 0; i < n_types; ++i) { check(type_ids[i] < cat->types.size(), "type id"); its.push_back(cat->types[type_ids[i]].get()); }
+    // getCapacityType: spot if the requirements admit it and an available offering is compatible with them pinned to spot
+    int ct = C.valOnDemand;
+    if (reqs.Get(C.keyCT).Has(C.valSpot)) {
+      Requirements pinned = reqs;
+      pinned.m.erase(C.keyCT);
+      pinned.m.emplace(C.keyCT, Requirement::New(C.keyCT, In, {C.valSpot}));
+      for (auto* it : its) {
+        for (auto& o : it->offerings) if (o.available && offeringCompatible(pinned, o, C)) { ct = C.valSpot; break; }
+        if (ct == C.valSpot) break;
+      }
+    }
+    *capacity_type = ct == C.valSpot ? KG_CT_SPOT : KG_CT_ON_DEMAND;
+    // getLaunchTemplateConfigs: requirements[capacity-type] = In [capacityType]; getOverrides over the available offerings
+    Requirements pinned = reqs;
+    pinned.m.erase(C.keyCT);
+    pinned.m.emplace(C.keyCT, Requirement::New(C.keyCT, In, {ct}));
+    std::map<int, uint32_t> zonal;  // zone -> subnet entry
+    for (uint32_t s = 0; s < n_subnet_zones; ++s) zonal.emplace(pr.in.id(string(kgdesc::str(pools->strings, subnet_zones[s]))), s);
+    uint32_t n = 0;
+    for (auto* it : its)
+      for (auto& o : it->offerings) {
+        if (!o.available || !offeringCompatible(pinned, o, C)) continue;
+        auto f = zonal.find(o.reqs.Get(C.keyZone).Any());
+        if (f == zonal.end()) continue;
+        if (n < cap) out[n] = kg_override{(uint32_t)it->index, f->second};
+        n++;
+      }
+    *n_out = n;
+    return n > cap ? KG_ENOMEM : KG_OK;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "ko_launch_overrides: %s\n", e.what());
     return KG_EINVAL;
   }
 }

@@ -137,6 +137,23 @@ def test_launch_filter_and_truncate(L):
     check_reference_pins(L)
 
 
+def test_launch_overrides(L):
+    from tests.launch_common import check_overrides
+    check_overrides(L)
+
+
+def test_ice_cache_and_capacity_type_outcomes(L):
+    """The reference's ICE-cache and capacity-type scenarios end to end through the C ABI: kg_solve -> kg_launch_filter ->
+    kg_launch_overrides -> (fake fleet) -> kg_catalog_update_offerings -> kg_solve."""
+    from tests.launch_common import LibraryBackend, check_ice_and_capacity_type
+    check_ice_and_capacity_type(lambda types: LibraryBackend(L, types))
+
+
+def test_min_values_createfleet_requests(L):
+    from tests.launch_common import LibraryBackend, check_min_values_launches
+    check_min_values_launches(lambda types: LibraryBackend(L, types))
+
+
 def test_catalog_build_ec2(L):
     from tests.catalog_common import check_ec2_build
     check_ec2_build(L)

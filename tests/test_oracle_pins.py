@@ -169,3 +169,16 @@ def test_well_known_label_selectors_schedule():
     p["node_selector"] = {wl.L_IT: "g4dn.8xlarge"}
     res = solve(types, [p], OD_POOL)
     assert [types[t]["name"] for t in res["claims"][0]["types"]] == ["g4dn.8xlarge"]
+
+
+def test_ice_cache_and_capacity_type_outcomes():
+    """instancetype/suite_test.go:1901-2114, 2117-2184 on the oracle (Solve, launch filter, getCapacityType / getOverrides)
+    with the fake CreateFleet's behaviour restated in tests/launch_common.py::provision."""
+    from tests.launch_common import OracleBackend, check_ice_and_capacity_type
+    check_ice_and_capacity_type(OracleBackend)
+
+
+def test_min_values_createfleet_requests():
+    """cloudprovider/suite_test.go:285-590 on the oracle."""
+    from tests.launch_common import OracleBackend, check_min_values_launches
+    check_min_values_launches(OracleBackend)
