@@ -262,7 +262,11 @@ typedef struct {
   uint8_t has_limits;
   kg_range limits;          /* pools.quantities */
   kg_range daemon_overhead; /* pools.quantities: requests of daemonset pods that fit the template */
-  uint32_t catalog;         /* index into the catalogs[] passed alongside */
+  uint32_t catalog;         /* index into the catalogs[] passed alongside: the InstanceTypes of this NodePool's EC2NodeClass
+                               (cloudprovider.go:172-190); NodePools may name different catalogs in one call */
+  uint64_t catalog_generation; /* the List() cache key (instancetype.go:127-136) the caller resolved for this NodePool; when
+                                  non-zero and different from the generation the resident catalog carries, the call returns
+                                  KG_ESTALE and changes nothing (upload / kg_catalog_update_offerings first).  0 = not checked */
 } kg_nodepool;
 
 typedef struct {
@@ -494,9 +498,10 @@ int32_t kg_consolidate_multi(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t 
                              const kg_pods_desc* pending, const kg_nodepools_desc* nodepools,
                              const kg_candidates_desc* cands, kg_candidate_record* records, uint32_t cap_records,
                              uint32_t* n_records, double* device_ms);
-/* first-wins (single) / binary-search replay (multi) over records gathered from all shards. */
-int32_t kg_consolidate_select(kg_ctx* ctx, kg_catalog* catalog, int32_t multi, const kg_candidate_record* records, uint32_t n_records,
-                              uint32_t n_candidates, kg_decision* out);
+/* first-wins (single) / binary-search replay (multi) over records gathered from all shards.  `catalogs` = the array the
+ * records were computed with; the decision's type ids index the catalog of its (replacement) nodepool. */
+int32_t kg_consolidate_select(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, int32_t multi, const kg_candidate_record* records,
+                              uint32_t n_records, uint32_t n_candidates, kg_decision* out);
 /* Validation re-simulation (Appendix A.9 "wait 15 s, recompute candidates, re-simulate, require the
  * same outcome"): the caller uploads a FRESH cluster snapshot and passes the command it is about to execute -- its
  * candidate nodes (indices into the fresh snapshot, at most 101: the longest prefix the multi-node search probes), KG_DECISION_DELETE / _REPLACE and, for a replace, the

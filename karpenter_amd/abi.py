@@ -40,7 +40,8 @@ POD = np.dtype([("uid", "<u4"), ("ns", "<u4"), ("creation_ts", "<i8"), ("labels"
 NODE = np.dtype([("name", "<u4"), ("labels", RANGE), ("taints", RANGE), ("available", RANGE), ("capacity", RANGE),
                  ("daemon_requests", RANGE), ("initialized", "u1"), ("managed", "u1"), ("deleting", "u1"), ("price", "<f8")], align=True)
 NODEPOOL = np.dtype([("name", "<u4"), ("weight", "<i4"), ("requirements", RANGE), ("labels", RANGE), ("taints", RANGE),
-                     ("has_limits", "u1"), ("limits", RANGE), ("daemon_overhead", RANGE), ("catalog", "<u4")], align=True)
+                     ("has_limits", "u1"), ("limits", RANGE), ("daemon_overhead", RANGE), ("catalog", "<u4"),
+                     ("catalog_generation", "<u8")], align=True)
 CLAIM_OUT = np.dtype([("nodepool", "<u4"), ("n_pods", "<u4"), ("types", RANGE), ("requirements", RANGE), ("requests", RANGE),
                       ("truncation_failed", "u1")], align=True)
 REQ_OUT = np.dtype([("key", "<u4"), ("complement", "u1"), ("has_gt", "u1"), ("has_lt", "u1"), ("gt", "<i8"), ("lt", "<i8"),
@@ -364,7 +365,8 @@ def build_nodepools(nodepools, well_known, max_instance_types=60):
         lim = np_.get("limits")
         rows.append((pb.s(np_["name"]), int(np_.get("weight", 0)), pb.req_list(np_.get("requirements")),
                      pb.label_list(np_.get("labels")), pb.taint_list(np_.get("taints")), 1 if lim else 0,
-                     pb.quantity_list(lim), pb.quantity_list(np_.get("daemon_overhead")), int(np_.get("catalog", 0))))
+                     pb.quantity_list(lim), pb.quantity_list(np_.get("daemon_overhead")), int(np_.get("catalog", 0)),
+                     int(np_.get("catalog_generation", 0))))
     wk = pb.values(well_known)
     a = np.array(rows, dtype=NODEPOOL) if rows else np.zeros(0, NODEPOOL)
     d = NodePoolsDesc()

@@ -35,8 +35,15 @@ struct kg_ctx {
     if (pool.size() >= 6) { kg::hal::dfree(pool.front().ptr); pool.erase(pool.begin()); }
     pool.push_back(kg::DeviceBuffer{p, bytes});
   }
-  ~kg_ctx() { for (auto& b : pool) kg::hal::dfree(b.ptr); }
+  // merged views of the catalog sets recent solves named (at most 2 kept); owned by the context
+  std::vector<kg_catalog*> merged;
+  uint64_t merged_clock = 0;
+  ~kg_ctx() {
+    for (auto& b : pool) kg::hal::dfree(b.ptr);
+    for (auto* m : merged) { kg::hal::dfree(m->tab.dev.ptr); delete m; }
+  }
   uint32_t kHostname, kZone, kCT, kZid, kNodePool, kInstanceType;
+  uint32_t kPart;  // hidden label key of merged catalog views ("karpgpu.internal/catalog")
   uint32_t rCPU, rMemory, rPods;
 };
 

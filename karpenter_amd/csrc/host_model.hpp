@@ -27,6 +27,9 @@ namespace kg {
 struct Unsupported : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
+struct Stale : std::runtime_error {  // -> KG_ESTALE
+  using std::runtime_error::runtime_error;
+};
 
 struct StrMap {
   std::vector<std::string> strs;
@@ -245,4 +248,10 @@ struct kg_catalog {
   static uint64_t next_uid() { static std::atomic<uint64_t> n{1}; return n.fetch_add(1); }
   std::vector<kg::CatType> types;
   kg::CatalogTables tab;
+  // A merged view over several uploaded catalogs (NodePools on different EC2NodeClasses in one solve): `types` is their
+  // concatenation, every type carrying a hidden requirement that names its source.  Empty for an uploaded catalog.
+  std::vector<uint32_t> part_begin;  // [parts + 1] first merged type id of every source
+  std::vector<uint64_t> part_key;    // (uid, generation, tab_epoch) per source: what the view was built from
+  uint64_t last_use = 0;
+  uint32_t part_of(uint32_t t) const { uint32_t p = 0; while (p + 2 < part_begin.size() && t >= part_begin[p + 1]) ++p; return p; }
 };

@@ -186,6 +186,7 @@ namespace {
 
 struct Template {
   uint32_t index;  // nodepool index in the descriptor
+  uint32_t part = 0;  // which source catalog its instance types come from (merged views; 0 otherwise)
   std::string name;
   int weight;
   HReqs reqs;       // NodeClaimTemplate requirements
@@ -380,6 +381,54 @@ static HReqs pod_requirements(const Vocab& V, const PodClass& c, const RelaxStat
   return r;
 }
 
+// The catalog a call compiles against: the one catalog passed, or a merged view of the several passed (GetInstanceTypes is
+// resolved per NodePool through its own EC2NodeClass, cloudprovider.go:172-190, 254-265: NodePools may name different
+// catalogs).  The view is kept with the context, keyed on the identity of what it was built from.
+static kg_catalog* catalog_view(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs) {
+  for (uint32_t k = 0; k < n_catalogs; ++k) check(catalogs[k] && catalogs[k]->ctx == ctx && catalogs[k]->part_begin.empty(), "catalog handle");
+  if (n_catalogs == 1) return catalogs[0];
+  std::vector<uint64_t> key;
+  for (uint32_t k = 0; k < n_catalogs; ++k) { key.push_back(catalogs[k]->uid); key.push_back(catalogs[k]->generation); key.push_back(catalogs[k]->tab_epoch); }
+  for (auto* m : ctx->merged) if (m->part_key == key) { m->last_use = ++ctx->merged_clock; return m; }
+  if (n_catalogs > 60) throw Unsupported("more than 60 catalogs in one call");
+  std::unique_ptr<kg_catalog> m(new kg_catalog());
+  m->ctx = ctx;
+  m->generation = 0;
+  m->part_key = key;
+  Vocab& V = ctx->V;
+  for (uint32_t k = 0; k < n_catalogs; ++k) {
+    m->part_begin.push_back((uint32_t)m->types.size());
+    const uint32_t pv = V.val(ctx->kPart, "c" + std::to_string(k));
+    for (const CatType& t : catalogs[k]->types) {
+      m->types.push_back(t);
+      m->types.back().reqs.add(V, hreq_new(V, ctx->kPart, KG_OP_IN, {pv}, -1));
+    }
+  }
+  m->part_begin.push_back((uint32_t)m->types.size());
+  build_catalog_tables(ctx, m.get());
+  if (ctx->merged.size() >= 2) {
+    const size_t old = ctx->merged[0]->last_use <= ctx->merged[1]->last_use ? 0 : 1;
+    hal::dfree(ctx->merged[old]->tab.dev.ptr);
+    delete ctx->merged[old];
+    ctx->merged.erase(ctx->merged.begin() + old);
+  }
+  m->last_use = ++ctx->merged_clock;
+  ctx->merged.push_back(m.release());
+  return ctx->merged.back();
+}
+// ... for a call that names NodePools: their catalog indices and the generation each expects are checked first (KG_ESTALE)
+static kg_catalog* effective_catalog(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, const kg_nodepools_desc* nps) {
+  for (uint32_t i = 0; i < nps->n_nodepools; ++i) {
+    const kg_nodepool& q = nps->nodepools[i];
+    check(q.catalog < n_catalogs && catalogs[q.catalog], "nodepool catalog index");
+    const kg_catalog* c = catalogs[q.catalog];
+    if (q.catalog_generation != 0 && q.catalog_generation != c->generation)
+      throw Stale("nodepool " + std::to_string(i) + " expects catalog generation " + std::to_string(q.catalog_generation) + ", the resident catalog has " +
+                  std::to_string(c->generation) + ": upload or update it first");
+  }
+  return catalog_view(ctx, catalogs, n_catalogs);
+}
+
 struct SolveInputs {
   kg_ctx* ctx;
   kg_catalog* cat;
@@ -442,7 +491,10 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     t.has_limits = q.has_limits != 0;
     t.limits = parse_rl(V, npp, q.limits);
     t.daemon = parse_rl(V, npp, q.daemon_overhead);
-    if (q.catalog != 0) throw Unsupported("nodepools must share one catalog on the device path");
+    if (!in.cat->part_begin.empty()) {  // merged view: the template's types are those of its own catalog
+      t.part = q.catalog;
+      t.reqs.add(V, hreq_new(V, ctx->kPart, KG_OP_IN, {V.val(ctx->kPart, "c" + std::to_string(q.catalog))}, -1));
+    }
     C.templates.push_back(std::move(t));
   }
   std::stable_sort(C.templates.begin(), C.templates.end(), [](const Template& a, const Template& b) { return a.weight > b.weight; });
@@ -1446,6 +1498,7 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
 #define KG_GUARD_BEGIN try {
 #define KG_GUARD_END(ctx)                                                                   \
   } catch (const kg::Unsupported& e) { return fail(ctx, KG_EUNSUPPORTED, e.what()); }        \
+  catch (const kg::Stale& e) { return fail(ctx, KG_ESTALE, e.what()); }                      \
   catch (const kgdesc::DescError& e) { return fail(ctx, KG_EINVAL, e.what()); }              \
   catch (const std::bad_alloc&) { return fail(ctx, KG_ENOMEM, "out of host memory"); }       \
   catch (const std::length_error& e) { return fail(ctx, KG_ENOMEM, e.what()); }              \
@@ -1466,6 +1519,7 @@ int32_t kg_init(int32_t device, kg_ctx** out) {
   ctx->kZone = V.key("topology.kubernetes.io/zone");
   ctx->kCT = V.key("karpenter.sh/capacity-type");
   ctx->kZid = V.key("topology.k8s.aws/zone-id");
+  ctx->kPart = V.key("karpgpu.internal/catalog");
   ctx->kNodePool = V.key("karpenter.sh/nodepool");
   ctx->kInstanceType = V.key("node.kubernetes.io/instance-type");
   ctx->rCPU = V.resources.id("cpu");
@@ -1700,8 +1754,8 @@ int32_t kg_solve(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, 
   if (!ctx || !catalogs || n_catalogs == 0 || !pods || !nodepools || !out) return KG_EINVAL;
   CtxLock lk(ctx);
   KG_GUARD_BEGIN
-  if (n_catalogs != 1) throw Unsupported("one catalog per solve on the device path");
-  return solve_impl(ctx, catalogs, cluster, pods, nodepools, out, true);
+  kg_catalog* view = effective_catalog(ctx, catalogs, n_catalogs, nodepools);
+  return solve_impl(ctx, &view, cluster, pods, nodepools, out, true);
   KG_GUARD_END(ctx)
 }
 
@@ -1712,10 +1766,11 @@ int32_t kg_solve_noalloc(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_ca
   if (!ctx || !catalogs || n_catalogs == 0 || !pods || !nodepools || !out) return KG_EINVAL;
   CtxLock lk(ctx);
   KG_GUARD_BEGIN
-  if (n_catalogs != 1) throw Unsupported("one catalog per solve on the device path");
+  if (n_catalogs != 1) throw Unsupported("kg_solve_noalloc: one catalog per solve (a merged view of several has to be built: an allocation)");
+  kg_catalog* view = effective_catalog(ctx, catalogs, n_catalogs, nodepools);
   FixedArena fa;
   fa.base = (uint8_t*)hal::scratch_ptr(&fa.cap);
-  return solve_impl(ctx, catalogs, cluster, pods, nodepools, out, true, &fa);
+  return solve_impl(ctx, &view, cluster, pods, nodepools, out, true, &fa);
   KG_GUARD_END(ctx)
 }
 
@@ -1872,11 +1927,13 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
     co.truncation_failed = trunc_failed[c];
     co.types.begin = out->needed_type_ids;
     co.types.count = (uint32_t)cv.types.size();
-    for (uint32_t t : cv.types) W.add_type(t);
+    const uint32_t type_base = catalogs[0]->part_begin.empty() ? 0 : catalogs[0]->part_begin[tp.part];  // (merged view -> ids of the NodePool's own catalog)
+    for (uint32_t t : cv.types) W.add_type(t - type_base);
     // requirements, keys and values in lexicographic order
     std::sort(creqs.begin(), creqs.end(), [&](const HReq& a, const HReq& b) { return V.keys.strs[a.key] < V.keys.strs[b.key]; });
     std::vector<kg_req_out> tmp;
     for (auto& r : creqs) {
+      if (r.key == ctx->kPart) continue;  // (the merged view's own bookkeeping, not a label)
       kg_req_out q{};
       q.key = W.add_string(V.keys.strs[r.key]);
       q.complement = r.compl_;
@@ -2206,22 +2263,33 @@ static std::unique_ptr<kg_cons_plan> build_cons_plan(kg_ctx* ctx, kg_catalog* ca
   const int gspot = V.vals[ctx->kCT].find("spot"), god = V.vals[ctx->kCT].find("on-demand");
   PL.spot = gspot < 0 ? -1 : cat->tab.local(ctx->kCT, (uint32_t)gspot);
   PL.od = god < 0 ? -1 : cat->tab.local(ctx->kCT, (uint32_t)god);
+  // (a candidate's instance type is resolved among the types of ITS NodePool: instanceTypeMap[nodePool][name] upstream)
   std::unordered_map<std::string, int> type_by_name;
-  for (size_t t = 0; t < cat->types.size(); ++t) type_by_name.emplace(cat->types[t].name, (int)t);
+  for (size_t t = 0; t < cat->types.size(); ++t) type_by_name.emplace(std::to_string(cat->part_begin.empty() ? 0 : cat->part_of((uint32_t)t)) + "/" + cat->types[t].name, (int)t);
+  std::unordered_map<std::string, uint32_t> part_of_pool;
+  for (uint32_t i = 0; i < nodepools->n_nodepools; ++i)
+    part_of_pool.emplace(std::string(kgdesc::str(nodepools->pools.strings, nodepools->nodepools[i].name)), cat->part_begin.empty() ? 0 : nodepools->nodepools[i].catalog);
   PL.cinfo.assign(n_used, CandInfo());
   for (uint32_t i = 0; i < n_used; ++i) {
     const CNode& nd = cluster->nodes[cands->candidates[i]];
-    int zone = -1, ctv = -1, zid = -1, itv = -1;
+    int zone = -1, ctv = -1, zid = -1, itv = -1, npv = -1;
     for (auto& kv : nd.labels) {
       if (kv.first == ctx->kZone) zone = (int)kv.second;
       if (kv.first == ctx->kCT) ctv = (int)kv.second;
       if (kv.first == ctx->kZid) zid = (int)kv.second;
       if (kv.first == ctx->kInstanceType) itv = (int)kv.second;
+      if (kv.first == ctx->kNodePool) npv = (int)kv.second;
     }
     CandInfo& ci = PL.cinfo[i];
     ci.spot = ctv >= 0 && ctv == gspot;
     if (itv < 0) continue;
-    auto f = type_by_name.find(V.vals[ctx->kInstanceType].strs[itv]);
+    uint32_t part = 0;
+    if (!cat->part_begin.empty()) {
+      auto pf = npv < 0 ? part_of_pool.end() : part_of_pool.find(V.vals[ctx->kNodePool].strs[npv]);
+      if (pf == part_of_pool.end()) continue;  // (not a node of one of these NodePools: no instance type to price)
+      part = pf->second;
+    }
+    auto f = type_by_name.find(std::to_string(part) + "/" + V.vals[ctx->kInstanceType].strs[itv]);
     if (f == type_by_name.end()) continue;
     ci.type = f->second;
     for (auto& o : cat->types[ci.type].offerings) {
@@ -2241,8 +2309,8 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   if (!ctx || !catalogs || n_catalogs == 0 || !cluster || !nodepools || !cands || !n_records || (!records && cap_records)) return KG_EINVAL;
   CtxLock lk(ctx);
   KG_GUARD_BEGIN
-  if (n_catalogs != 1) throw Unsupported("one catalog per solve on the device path");
-  kg_catalog* cat = catalogs[0];
+  kg_catalog* cat = effective_catalog(ctx, catalogs, n_catalogs, nodepools);
+  if (cat->types.size() > (size_t)KG_RECORD_TYPE_WORDS * 64) throw Unsupported("consolidation over more than 1024 instance types (all catalogs of the call together)");
   const uint32_t n = cands->n_candidates;
   const int shards = std::max(cands->n_shards, 1);
   check(cands->shard >= 0 && cands->shard < shards, "shard index");
@@ -2259,7 +2327,8 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
     PLp = one_off.get();
   } else {
     Hasher H;
-    H.u64(cat->uid); H.u64(cat->generation); H.u64(cat->tab_epoch); H.u64((uint64_t)(uintptr_t)cat->tab.dev.ptr); H.u64(ctx->V.resources.size());
+    for (uint32_t k = 0; k < n_catalogs; ++k) { H.u64(catalogs[k]->uid); H.u64(catalogs[k]->generation); H.u64(catalogs[k]->tab_epoch); }
+    H.u64((uint64_t)(uintptr_t)cat->tab.dev.ptr); H.u64(ctx->V.resources.size());
     H.u64(multi); H.u64(ctx->collect_stats); H.u64((uint64_t)nodepools->max_instance_types);
     H.arr(cands->candidates, n);
     H.pools(nodepools->pools); H.arr(nodepools->nodepools, nodepools->n_nodepools); H.u64(nodepools->well_known_labels.begin); H.u64(nodepools->well_known_labels.count);
@@ -2483,7 +2552,8 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
           double max_price = std::numeric_limits<double>::max();
           for (uint32_t t : rp.types)
             for (uint32_t ci = c0; ci < c1; ++ci)
-              if (cinfo[ci].ok && cinfo[ci].type == (int)t && cinfo[ci].price < max_price) max_price = cinfo[ci].price;
+              if (cinfo[ci].ok && cinfo[ci].price < max_price &&  // (upstream keys on the instance type NAME: across catalogs too)
+                  (cinfo[ci].type == (int)t || (!cat->part_begin.empty() && cat->types[cinfo[ci].type].name == cat->types[t].name))) max_price = cinfo[ci].price;
           remove_by_price(cat, &rp, max_price, spot, od);  // (its minValues error is swallowed upstream)
           if (rp.types.empty()) rp.decision = KG_DECISION_NOOP;
         }
@@ -2552,11 +2622,12 @@ int32_t kg_consolidate_validate(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
 
 // SingleNodeConsolidation.ComputeCommand (first candidate in order with a command) / the binary search of
 // MultiNodeConsolidation.firstNConsolidationOption, replayed over records gathered from every shard.
-int32_t kg_consolidate_select(kg_ctx* ctx, kg_catalog* catalog, int32_t multi, const kg_candidate_record* records, uint32_t n_records,
-                              uint32_t n_candidates, kg_decision* out) {
-  if (!ctx || !catalog || !out || (!records && n_records)) return KG_EINVAL;
+int32_t kg_consolidate_select(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, int32_t multi, const kg_candidate_record* records,
+                              uint32_t n_records, uint32_t n_candidates, kg_decision* out) {
+  if (!ctx || !catalogs || n_catalogs == 0 || !out || (!records && n_records)) return KG_EINVAL;
   CtxLock lk(ctx);
   KG_GUARD_BEGIN
+  kg_catalog* catalog = catalog_view(ctx, catalogs, n_catalogs);  // (the view the records' type ids and masks refer to)
   const kg_candidate_record* win = nullptr;
   int win_n = 0;
   if (!multi) {
@@ -2589,7 +2660,9 @@ int32_t kg_consolidate_select(kg_ctx* ctx, kg_catalog* catalog, int32_t multi, c
       for (uint64_t m = win->type_mask[w]; m; m &= m - 1) types.push_back((uint32_t)(w * 64 + __builtin_ctzll(m)));
     for (uint32_t t : types) check(t < catalog->types.size(), "record type id outside the catalog");
     order_by_price(catalog, &types, win->zone_mask, win->ct_mask);
-    for (uint32_t t : types) { if (out->n_types < out->cap_type_ids && out->type_ids) out->type_ids[out->n_types] = t; out->n_types++; }
+    // (several catalogs: ids of the replacement NodePool's own catalog -- one claim, one NodePool, one catalog)
+    const uint32_t base = catalog->part_begin.empty() || types.empty() ? 0 : catalog->part_begin[catalog->part_of(types[0])];
+    for (uint32_t t : types) { if (out->n_types < out->cap_type_ids && out->type_ids) out->type_ids[out->n_types] = t - base; out->n_types++; }
   }
   return KG_OK;
   KG_GUARD_END(ctx)

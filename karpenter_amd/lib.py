@@ -53,7 +53,7 @@ class Library:
                                           C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         d.kg_truncate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, abi.Range, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p,
                                   C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
-        d.kg_consolidate_select.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        d.kg_consolidate_select.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         d.kg_set_collect_stats.argtypes = [C.c_void_p, C.c_int32]
         self.ctx = C.c_void_p()
         st = d.kg_init(device, C.byref(self.ctx))
@@ -179,8 +179,11 @@ class Library:
         return recs[:k.value], ms.value
 
     def consolidate_select(self, catalog, records, n_candidates, multi, cap_types=1024):
+        """`catalog`: one handle, or the list of handles the records were computed with."""
+        cats = list(catalog) if isinstance(catalog, (list, tuple)) else [catalog]
+        arr = (C.c_void_p * len(cats))(*cats)
         db = abi.DecisionBuffer(cap_types)
-        self._check(self.dll.kg_consolidate_select(self.ctx, catalog, 1 if multi else 0, records.ctypes.data if len(records) else None,
+        self._check(self.dll.kg_consolidate_select(self.ctx, arr, len(cats), 1 if multi else 0, records.ctypes.data if len(records) else None,
                                                    len(records), n_candidates, C.addressof(db.dec)))
         return db.decode()
 

@@ -1307,9 +1307,14 @@ static bool candidatePrice(Problem& pr, int node, double* price) {
   auto& cn = pr.nodes[node];
   auto itl = cn.labels.find(C.keyInstanceType);
   if (itl == cn.labels.end()) return false;
+  // NewCandidate: instanceTypeMap[nodePool.Name][instance-type label] -- the type as ITS NodePool's catalog lists it
   const InstanceType* ty = nullptr;
-  for (auto& cat : pr.catalogs)
-    for (auto& t : cat->types) if (t->name == itl->second) { ty = t.get(); break; }
+  const Catalog* cat = pr.catalogs.size() == 1 ? pr.catalogs[0].get() : nullptr;
+  auto npl = cn.labels.find(C.keyNodePool);
+  if (npl != cn.labels.end())
+    for (auto& np : pr.pools) if (np->name == npl->second) cat = np->catalog;
+  if (!cat) return false;
+  for (auto& t : cat->types) if (t->name == itl->second) { ty = t.get(); break; }
   if (!ty) return false;
   vector<std::pair<int, int>> ls(cn.labels.begin(), cn.labels.end());
   Requirements nodeReqs = NewLabelRequirements(ls);

@@ -234,3 +234,18 @@ def test_wave_kernel_scan_order_beyond_lds(LW):
     small = wl.mixed_pods(600, 8, zones, families(types), prefix="small")
     ro, rg = _check_wave(LW, Problem(types, big + small, [wl.default_nodepool()]))
     assert rg.res.n_claims > 4096
+
+
+def test_multi_catalog_solve(L):
+    from tests.multicat_common import check_multi_catalog_solve
+    check_multi_catalog_solve(L)
+
+
+def test_multi_catalog_consolidation(L):
+    from tests.multicat_common import check_multi_catalog_consolidation
+    check_multi_catalog_consolidation(L)
+
+
+def test_stale_catalog_generation(L):
+    from tests.multicat_common import check_stale_generation
+    check_stale_generation(L)

@@ -163,3 +163,18 @@ def test_catalog_update_offerings_in_place(L):
     """ICE marks / spot price moves patched into the resident catalog == fresh upload of the rebuilt catalog == oracle."""
     from tests.update_common import check_updates
     check_updates(L)
+
+
+def test_multi_catalog_solve(L):
+    from tests.multicat_common import check_multi_catalog_solve
+    check_multi_catalog_solve(L)
+
+
+def test_multi_catalog_consolidation(L):
+    from tests.multicat_common import check_multi_catalog_consolidation
+    check_multi_catalog_consolidation(L)
+
+
+def test_stale_catalog_generation(L):
+    from tests.multicat_common import check_stale_generation
+    check_stale_generation(L)
