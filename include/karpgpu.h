@@ -376,6 +376,7 @@ typedef struct kg_cluster kg_cluster;
 
 /* lifecycle.  device < 0 -> current device.  Fails (KG_EDEVICE) when no GPU is present. */
 int32_t kg_init(int32_t device, kg_ctx** out);
+int32_t kg_device_count(int32_t* n); /* visible GPUs */
 int32_t kg_destroy(kg_ctx* ctx);
 int32_t kg_last_error(kg_ctx* ctx, char* buf, size_t n);
 int32_t kg_stats_get(kg_ctx* ctx, kg_stats* out);
@@ -511,6 +512,35 @@ int32_t kg_consolidate_select(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t
 int32_t kg_consolidate_validate(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, kg_cluster* cluster, const kg_pods_desc* pending,
                                 const kg_nodepools_desc* nodepools, const int32_t* candidates, uint32_t n_candidates, int32_t decision,
                                 const uint32_t* type_ids, uint32_t n_types, uint8_t* valid, double* device_ms);
+
+/* ---------------------------------------------------------------- several GPUs, one process
+ * The reference's disruption controller is one Go process; a kg_group lets it use every GPU of the node without a second
+ * process or a collective library: one context and one worker thread per device.  Catalogs and cluster snapshots are
+ * replicated (the *_upload calls below fill an array of n_devices handles, device i's at [i]); kg_group_consolidate deals
+ * the units of a round round-robin (unit k -> device k mod n_devices), runs every shard at once, gathers the records in this
+ * process and replays the reference's selection (kg_consolidate_select) -- the same decision as one device, or as the
+ * reference's sequential loop.  Scheduler.Solve does not shard (a chain of dependent placements): use kg_group_context(g, i)
+ * with kg_solve for replicas.  One group call runs at a time; the contexts stay usable on their own from other threads. */
+typedef struct kg_group kg_group;
+/* devices == NULL: the first n_devices visible devices, or every visible device when n_devices == 0.  A device may be named
+ * more than once (several contexts on one GPU, each with its own stream). */
+int32_t kg_group_init(const int32_t* devices, uint32_t n_devices, kg_group** out);
+int32_t kg_group_destroy(kg_group* g);
+int32_t kg_group_size(kg_group* g, uint32_t* n_devices);
+int32_t kg_group_context(kg_group* g, uint32_t i, kg_ctx** out);
+int32_t kg_group_last_error(kg_group* g, char* buf, size_t n);
+int32_t kg_group_catalog_upload(kg_group* g, const kg_catalog_desc* desc, uint64_t generation, kg_catalog** out /* [n_devices] */);
+int32_t kg_group_catalog_update_offerings(kg_group* g, kg_catalog* const* catalogs /* [n_devices] */, const kg_strtab* strings,
+                                          const kg_offering_update* updates, uint32_t n_updates, uint64_t generation);
+int32_t kg_group_catalog_free(kg_group* g, kg_catalog* const* catalogs /* [n_devices] */);
+int32_t kg_group_cluster_upload(kg_group* g, const kg_cluster_desc* desc, kg_cluster** out /* [n_devices] */);
+int32_t kg_group_cluster_free(kg_group* g, kg_cluster* const* clusters /* [n_devices] */);
+/* SingleNodeConsolidation.ComputeCommand / MultiNodeConsolidation.firstNConsolidationOption over all devices of the group.
+ * catalogs = [n_devices][n_catalogs] (device-major), clusters = [n_devices]; cands->shard / n_shards are ignored.  records
+ * (may be NULL) receives the gathered per-unit records; *device_ms = the slowest device's kernel time. */
+int32_t kg_group_consolidate(kg_group* g, kg_catalog* const* catalogs, uint32_t n_catalogs, kg_cluster* const* clusters,
+                             const kg_pods_desc* pending, const kg_nodepools_desc* nodepools, const kg_candidates_desc* cands, int32_t multi,
+                             kg_candidate_record* records, uint32_t cap_records, uint32_t* n_records, kg_decision* out, double* device_ms);
 
 #ifdef __cplusplus
 }

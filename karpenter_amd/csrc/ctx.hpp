@@ -19,6 +19,7 @@ struct kg_ctx {
   bool collect_stats = true;  // maintain the reference-visit counters (exact; costs an extra pass per placement)
   std::mutex mu;
   int device = 0;  // the GPU this context lives on (made current by every entry point)
+  void* stream = nullptr;  // the context's own HIP stream: all of its copies and kernels (two contexts overlap on one GPU)
   // Device buffers of finished solves, kept for the next one (a Solve needs three; hipMalloc / hipFree per call cost more
   // than the kernels of a small batch).  Used under `mu` only.
   std::vector<kg::DeviceBuffer> pool;
@@ -51,7 +52,7 @@ namespace kg {
 // context lock + the context's device made current for the calling thread
 struct CtxLock {
   std::lock_guard<std::mutex> lk;
-  explicit CtxLock(kg_ctx* c) : lk(c->mu) { hal::use_device(c->device); }
+  explicit CtxLock(kg_ctx* c) : lk(c->mu) { hal::use_device(c->device, c->stream); }
 };
 // A fixed region of device memory that a solve carves its tables from instead of the context's pool (kg_solve_noalloc: the
 // library's static scratch array).  Nothing is ever allocated or freed; exceeding it is an error.

@@ -170,6 +170,9 @@ constexpr int KG_MAX_DEVICES = 64;
 static std::mutex g_dev_mu;
 static void* g_scratch_ptr[KG_MAX_DEVICES];             // per device: address of ITS copy of `scratch`
 static std::vector<hipEvent_t> g_events[KG_MAX_DEVICES];  // per device: timing events, created at init and reused
+// The stream of the context whose entry point the calling thread is in (set with the device by CtxLock): every copy, fill,
+// launch and event of the call goes to it, so calls on different contexts overlap on the GPU and none touches the null stream.
+static thread_local hipStream_t t_stream = nullptr;
 
 std::string init(int device, int* device_out) {
   int n = 0;
@@ -199,7 +202,20 @@ std::string init(int device, int* device_out) {
   }
   return "";
 }
-void use_device(int device) { (void)hipSetDevice(device); }
+void use_device(int device, void* stream) {
+  (void)hipSetDevice(device);
+  t_stream = (hipStream_t)stream;
+}
+int device_count() {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+void* stream_create() {
+  hipStream_t s = nullptr;
+  ck(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+  return s;
+}
+void stream_destroy(void* s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
 void* scratch_ptr(size_t* bytes) {
   int dev = 0;
   ck(hipGetDevice(&dev), "hipGetDevice");
@@ -214,10 +230,19 @@ void* dmalloc(size_t bytes) {
   return p;
 }
 void dfree(void* p) { if (p) (void)hipFree(p); }
-void h2d(void* dst, const void* src, size_t bytes) { if (bytes) ck(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "hipMemcpy H2D"); }
-void d2h(void* dst, const void* src, size_t bytes) { if (bytes) ck(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost), "hipMemcpy D2H"); }
-void dzero(void* dst, size_t bytes) { if (bytes) ck(hipMemset(dst, 0, bytes), "hipMemset"); }
-void dfill(void* dst, int byte, size_t bytes) { if (bytes) ck(hipMemset(dst, byte, bytes), "hipMemset"); }
+// (copies complete before they return: the callers hand over pageable host buffers they reuse at once)
+void h2d(void* dst, const void* src, size_t bytes) {
+  if (!bytes) return;
+  ck(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, t_stream), "hipMemcpy H2D");
+  ck(hipStreamSynchronize(t_stream), "hipMemcpy H2D");
+}
+void d2h(void* dst, const void* src, size_t bytes) {
+  if (!bytes) return;
+  ck(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, t_stream), "hipMemcpy D2H");
+  ck(hipStreamSynchronize(t_stream), "hipMemcpy D2H");
+}
+void dzero(void* dst, size_t bytes) { if (bytes) ck(hipMemsetAsync(dst, 0, bytes, t_stream), "hipMemset"); }
+void dfill(void* dst, int byte, size_t bytes) { if (bytes) ck(hipMemsetAsync(dst, byte, bytes, t_stream), "hipMemset"); }
 
 // HIP-event bracket of one launch group; the events come from the device's pool (created at kg_init) and go back to it
 struct Timer {
@@ -235,10 +260,10 @@ struct Timer {
   Timer() {
     ck(hipGetDevice(&dev), "hipGetDevice");
     a = take(dev); b = take(dev);
-    ck(hipEventRecord(a, 0), "record");
+    ck(hipEventRecord(a, t_stream), "record");
   }
   float stop() {
-    ck(hipEventRecord(b, 0), "record");
+    ck(hipEventRecord(b, t_stream), "record");
     ck(hipEventSynchronize(b), "kernel execution");
     float ms = 0;
     ck(hipEventElapsedTime(&ms, a, b), "elapsed");
@@ -251,12 +276,12 @@ struct Timer {
 void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms) {
   Timer t;
   const uint32_t total = X.E * (uint32_t)P.TW;
-  if (total) hipLaunchKernelGGL(k_type_filter, dim3((total + 255) / 256), dim3(256), 0, 0, P, X);
-  if (P.N > 0 && P.S > 0) hipLaunchKernelGGL(k_node_static, dim3((P.N + 255) / 256, P.S), dim3(256), 0, 0, P, X);
+  if (total) hipLaunchKernelGGL(k_type_filter, dim3((total + 255) / 256), dim3(256), 0, t_stream, P, X);
+  if (P.N > 0 && P.S > 0) hipLaunchKernelGGL(k_node_static, dim3((P.N + 255) / 256, P.S), dim3(256), 0, t_stream, P, X);
   const uint32_t pm = (uint32_t)P.NV * (uint32_t)P.TW;
-  if (pm) hipLaunchKernelGGL(k_pod_mask, dim3((pm + 255) / 256), dim3(256), 0, 0, P, X);
+  if (pm) hipLaunchKernelGGL(k_pod_mask, dim3((pm + 255) / 256), dim3(256), 0, t_stream, P, X);
   const uint32_t pcw = (uint32_t)P.NV * (uint32_t)(sizeof(PodCtx) / 8);
-  if (pcw && X.pctx_out && P.TW <= KG_TWLDS) hipLaunchKernelGGL(k_pod_ctx, dim3((pcw + 255) / 256), dim3(256), 0, 0, P, X);
+  if (pcw && X.pctx_out && P.TW <= KG_TWLDS) hipLaunchKernelGGL(k_pod_ctx, dim3((pcw + 255) / 256), dim3(256), 0, t_stream, P, X);
   ck(hipGetLastError(), "prepass launch");
   *ms = t.stop();
 }
@@ -264,35 +289,35 @@ void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms) {
 void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int block, float* ms, bool batch) {
   Timer t;
   if (batch) {
-    if (block >= 512) hipLaunchKernelGGL((k_simulate<512>), dim3(nsims), dim3(512), 0, 0, P, sims, nqueue);
-    else hipLaunchKernelGGL((k_simulate<256>), dim3(nsims), dim3(256), 0, 0, P, sims, nqueue);
+    if (block >= 512) hipLaunchKernelGGL((k_simulate<512>), dim3(nsims), dim3(512), 0, t_stream, P, sims, nqueue);
+    else hipLaunchKernelGGL((k_simulate<256>), dim3(nsims), dim3(256), 0, t_stream, P, sims, nqueue);
     ck(hipGetLastError(), "simulate launch");
     *ms = t.stop();
     return;
   }
-  if (P.stats & (2 | 8)) hipLaunchKernelGGL((k_solve<256, true>), dim3(nsims), dim3(256), 0, 0, P, sims, nqueue);  // debug timers: 256 threads only
-  else if (block >= 1024) hipLaunchKernelGGL((k_solve<1024, false>), dim3(nsims), dim3(1024), 0, 0, P, sims, nqueue);
-  else if (block >= 512) hipLaunchKernelGGL((k_solve<512, false>), dim3(nsims), dim3(512), 0, 0, P, sims, nqueue);
-  else hipLaunchKernelGGL((k_solve<256, false>), dim3(nsims), dim3(256), 0, 0, P, sims, nqueue);
+  if (P.stats & (2 | 8)) hipLaunchKernelGGL((k_solve<256, true>), dim3(nsims), dim3(256), 0, t_stream, P, sims, nqueue);  // debug timers: 256 threads only
+  else if (block >= 1024) hipLaunchKernelGGL((k_solve<1024, false>), dim3(nsims), dim3(1024), 0, t_stream, P, sims, nqueue);
+  else if (block >= 512) hipLaunchKernelGGL((k_solve<512, false>), dim3(nsims), dim3(512), 0, t_stream, P, sims, nqueue);
+  else hipLaunchKernelGGL((k_solve<256, false>), dim3(nsims), dim3(256), 0, t_stream, P, sims, nqueue);
   ck(hipGetLastError(), "solve launch");
   *ms = t.stop();
 }
 void launch_solve_wave(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, float* ms) {
   Timer t;
-  if (P.stats & 8) hipLaunchKernelGGL((k_solve_wave<true>), dim3(nsims), dim3(64), 0, 0, P, sims, nqueue);
-  else hipLaunchKernelGGL((k_solve_wave<false>), dim3(nsims), dim3(64), 0, 0, P, sims, nqueue);
+  if (P.stats & 8) hipLaunchKernelGGL((k_solve_wave<true>), dim3(nsims), dim3(64), 0, t_stream, P, sims, nqueue);
+  else hipLaunchKernelGGL((k_solve_wave<false>), dim3(nsims), dim3(64), 0, t_stream, P, sims, nqueue);
   ck(hipGetLastError(), "solve (wave) launch");
   *ms = t.stop();
 }
 void launch_sim_init(const DevProblem& P, const SimBatch& B, float* ms) {
   Timer t;
-  if (B.nsims) hipLaunchKernelGGL(k_sim_init, dim3(B.nsims), dim3(256), 0, 0, P, B);
+  if (B.nsims) hipLaunchKernelGGL(k_sim_init, dim3(B.nsims), dim3(256), 0, t_stream, P, B);
   ck(hipGetLastError(), "sim init launch");
   *ms = t.stop();
 }
 void launch_sim_gather(const DevProblem& P, const SimBatch& B, const SimState* sims, float* ms) {
   Timer t;
-  if (B.nsims) hipLaunchKernelGGL(k_sim_gather, dim3((B.nsims + 63) / 64), dim3(64), 0, 0, P, B, sims);
+  if (B.nsims) hipLaunchKernelGGL(k_sim_gather, dim3((B.nsims + 63) / 64), dim3(64), 0, t_stream, P, B, sims);
   ck(hipGetLastError(), "sim gather launch");
   *ms = t.stop();
 }

@@ -4,12 +4,16 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 
 #include "hal.hpp"
 
 namespace kg::hal {
 std::string init(int, int* device_out) { *device_out = 0; return ""; }
-void use_device(int) {}
+void use_device(int, void*) {}
+int device_count() { return 1; }
+void* stream_create() { return nullptr; }
+void stream_destroy(void*) {}
 void* scratch_ptr(size_t* bytes) {
   static void* p = std::calloc(32u << 20, 1);  // (stands in for the device array of device.hip)
   *bytes = 32u << 20;
@@ -40,8 +44,9 @@ void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms) {
 
 void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int block, float* ms, bool) {
   auto t0 = std::chrono::steady_clock::now();
+  std::unique_ptr<Shared> shp(new Shared());  // (the workgroup's LDS; per call: contexts run on several threads at once)
+  Shared& sh = *shp;
   for (int i = 0; i < nsims; ++i) {
-    static Shared sh;
     std::memset(&sh, 0, sizeof sh);
     if (block >= 1024) solve_block<1024, false>(P, sims[i], sh, nqueue[i]);
     else if (block >= 512) solve_block<512, false>(P, sims[i], sh, nqueue[i]);

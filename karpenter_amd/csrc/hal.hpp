@@ -11,8 +11,12 @@ namespace kg::hal {
 // context lives on.  Set-up per device (once): the address of this device's copy of the library's static scratch array
 // (kg_solve_noalloc) and a few timing events, so that the no-allocation entry point never creates anything.
 std::string init(int device, int* device_out);
-// makes `device` current for the calling thread (every entry point, before it touches the GPU)
-void use_device(int device);
+// makes `device` current for the calling thread and `stream` (a context's own, from stream_create) the stream every HAL
+// operation of this thread goes to -- every entry point, before it touches the GPU
+void use_device(int device, void* stream);
+int device_count();     // visible GPUs (0 when there is none)
+void* stream_create();  // on the current device; never the null stream
+void stream_destroy(void* stream);
 // the current device's copy of the static scratch array and its size (device.hip: `scratch`)
 void* scratch_ptr(size_t* bytes);
 void* dmalloc(size_t bytes);

@@ -1514,6 +1514,14 @@ int32_t kg_init(int32_t device, kg_ctx** out) {
   if (!err.empty()) { fprintf(stderr, "kg_init: %s\n", err.c_str()); return KG_EDEVICE; }
   auto* ctx = new kg_ctx();
   ctx->device = dev;
+  try {
+    hal::use_device(dev, nullptr);
+    ctx->stream = hal::stream_create();
+  } catch (const std::exception& e) {
+    fprintf(stderr, "kg_init: %s\n", e.what());
+    delete ctx;
+    return KG_EDEVICE;
+  }
   Vocab& V = ctx->V;
   ctx->kHostname = V.key("kubernetes.io/hostname");
   ctx->kZone = V.key("topology.kubernetes.io/zone");
@@ -1529,9 +1537,20 @@ int32_t kg_init(int32_t device, kg_ctx** out) {
   return KG_OK;
 }
 
+int32_t kg_device_count(int32_t* n) {
+  if (!n) return KG_EINVAL;
+  *n = hal::device_count();
+  return KG_OK;
+}
+
 int32_t kg_destroy(kg_ctx* ctx) {
-  if (ctx) hal::use_device(ctx->device);  // (the pooled device buffers are freed on the context's GPU)
+  if (!ctx) return KG_OK;
+  void* stream = ctx->stream;
+  {
+    CtxLock lk(ctx);  // (the pooled device buffers are freed on the context's GPU; a call still running finishes first)
+  }
   delete ctx;
+  hal::stream_destroy(stream);
   return KG_OK;
 }
 

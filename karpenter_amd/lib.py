@@ -14,7 +14,9 @@ DEFAULT_PATH = os.path.join(_HERE, "libkarpgpu.so")
 
 EXPORTS = ["kg_init", "kg_destroy", "kg_last_error", "kg_stats_get", "kg_catalog_upload", "kg_catalog_build_ec2", "kg_catalog_update_offerings", "kg_candidates_order", "kg_consolidate_validate",
            "kg_catalog_query", "kg_catalog_size", "kg_catalog_free", "kg_cluster_upload", "kg_cluster_free", "kg_solve",
-           "kg_truncate", "kg_launch_filter", "kg_consolidate_single", "kg_consolidate_multi", "kg_consolidate_select", "kg_solve_noalloc", "kg_catalog_query_requirements", "kg_launch_overrides"]
+           "kg_truncate", "kg_launch_filter", "kg_consolidate_single", "kg_consolidate_multi", "kg_consolidate_select", "kg_solve_noalloc", "kg_catalog_query_requirements", "kg_launch_overrides",
+           "kg_device_count", "kg_group_init", "kg_group_destroy", "kg_group_size", "kg_group_context", "kg_group_last_error", "kg_group_catalog_upload",
+           "kg_group_catalog_update_offerings", "kg_group_catalog_free", "kg_group_cluster_upload", "kg_group_cluster_free", "kg_group_consolidate"]
 
 
 class KgError(RuntimeError):
@@ -223,3 +225,96 @@ class Library:
         if self.ctx:
             self.dll.kg_destroy(self.ctx)
             self.ctx = C.c_void_p()
+
+
+class Group:
+    """kg_group: one process, one context + worker thread per device (include/karpgpu.h, "several GPUs, one process")."""
+
+    def __init__(self, path=None, devices=None, n_devices=0):
+        path = path or DEFAULT_PATH
+        if not os.path.exists(path):
+            raise RuntimeError("libkarpgpu.so not built (%s): run __graft_entry__.build()" % path)
+        self.dll = d = C.CDLL(path)
+        d.kg_group_init.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        d.kg_group_destroy.argtypes = [C.c_void_p]
+        d.kg_group_size.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        d.kg_group_context.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        d.kg_group_last_error.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        d.kg_group_catalog_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        d.kg_group_catalog_update_offerings.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64]
+        d.kg_group_catalog_free.argtypes = [C.c_void_p, C.c_void_p]
+        d.kg_group_cluster_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        d.kg_group_cluster_free.argtypes = [C.c_void_p, C.c_void_p]
+        d.kg_group_consolidate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                           C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.POINTER(C.c_double)]
+        d.kg_stats_get.argtypes = [C.c_void_p, C.c_void_p]
+        d.kg_set_collect_stats.argtypes = [C.c_void_p, C.c_int32]
+        self.g = C.c_void_p()
+        if devices is not None:
+            arr = (C.c_int32 * len(devices))(*devices)
+            st = d.kg_group_init(arr, len(devices), C.byref(self.g))
+        else:
+            st = d.kg_group_init(None, n_devices, C.byref(self.g))
+        if st != 0:
+            raise KgError(st, "kg_group_init failed (no GPU?)")
+        n = C.c_uint32(0)
+        d.kg_group_size(self.g, C.byref(n))
+        self.n = n.value
+
+    def _check(self, st):
+        if st != 0:
+            buf = C.create_string_buffer(1024)
+            self.dll.kg_group_last_error(self.g, buf, 1024)
+            raise KgError(st, buf.value.decode("utf-8", "replace"))
+
+    def context(self, i):
+        h = C.c_void_p()
+        self._check(self.dll.kg_group_context(self.g, i, C.byref(h)))
+        return h
+
+    def set_collect_stats(self, enabled):
+        for i in range(self.n):
+            self.dll.kg_set_collect_stats(self.context(i), int(enabled))
+
+    def stats(self, i):
+        s = abi.Stats()
+        self.dll.kg_stats_get(self.context(i), C.addressof(s))
+        return s
+
+    def catalog_upload(self, built, generation=1):
+        hs = (C.c_void_p * self.n)()
+        self._check(self.dll.kg_group_catalog_upload(self.g, C.addressof(built.desc), generation, hs))
+        return hs
+
+    def catalog_update_offerings(self, handles, updates, generation):
+        st, a = abi.build_offering_updates(updates)
+        self._check(self.dll.kg_group_catalog_update_offerings(self.g, handles, C.addressof(st.desc), a.ctypes.data if len(a) else None, len(a), generation))
+
+    def catalog_free(self, handles):
+        self.dll.kg_group_catalog_free(self.g, handles)
+
+    def cluster_upload(self, built):
+        hs = (C.c_void_p * self.n)()
+        self._check(self.dll.kg_group_cluster_upload(self.g, C.addressof(built.desc), hs))
+        return hs
+
+    def cluster_free(self, handles):
+        self.dll.kg_group_cluster_free(self.g, handles)
+
+    def consolidate(self, catalogs, clusters, pending, nodepools, cands, multi, cap_types=1024, want_records=True):
+        """catalogs: list (one per catalog of the call) of per-device handle arrays -> (decision dict, records, device_ms)."""
+        import numpy as np
+        nc = len(catalogs)
+        arr = (C.c_void_p * (self.n * nc))(*[catalogs[k][i] for i in range(self.n) for k in range(nc)])
+        recs = np.zeros(max(cands.desc.n_candidates, 1) if want_records else 0, abi.CANDIDATE_RECORD)
+        k, ms = C.c_uint32(0), C.c_double(0)
+        db = abi.DecisionBuffer(cap_types)
+        self._check(self.dll.kg_group_consolidate(self.g, arr, nc, clusters, C.addressof(pending.desc), C.addressof(nodepools.desc), C.addressof(cands.desc),
+                                                  1 if multi else 0, recs.ctypes.data if want_records else None, recs.shape[0], C.byref(k),
+                                                  C.addressof(db.dec), C.byref(ms)))
+        return db.decode(), recs[:k.value], ms.value
+
+    def close(self):
+        if self.g:
+            self.dll.kg_group_destroy(self.g)
+            self.g = C.c_void_p()

@@ -44,3 +44,10 @@ def test_multi_node_more_than_100_candidates(L):
 def test_rounds_reuse_the_prepared_snapshot(L, name):
     from tests.cons_common import check_plan_reuse
     check_plan_reuse(L, name)
+
+
+@pytest.mark.parametrize("name", ["dense", "dense_pending"])
+def test_device_group_in_one_process(name):
+    """(emulation: every 'device' is the host; three contexts with a worker thread each)"""
+    from tests.group_common import check_group
+    assert check_group(EMU_PATH, [[0], [0, 0, 0]], name) == [1, 3]

@@ -40,3 +40,12 @@ def test_multi_node_more_than_100_candidates(L):
 def test_rounds_reuse_the_prepared_snapshot(L, name):
     from tests.cons_common import check_plan_reuse
     check_plan_reuse(L, name)
+
+
+def test_device_group_in_one_process():
+    """Every visible device (1 on the test box), then the same GPU three times: three contexts, three streams, three worker
+    threads whose simulations overlap on the one device."""
+    from karpenter_amd import lib as _lib
+    from tests.group_common import check_group
+    sizes = check_group(_lib.DEFAULT_PATH, [None, [0, 0, 0]])
+    assert sizes[0] >= 1 and sizes[1] == 3
