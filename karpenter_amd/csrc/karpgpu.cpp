@@ -1611,6 +1611,7 @@ int32_t kg_catalog_upload(kg_ctx* ctx, const kg_catalog_desc* desc, uint64_t gen
 
 int32_t kg_catalog_size(kg_catalog* cat, uint32_t* n_types, uint64_t* generation) {
   if (!cat) return KG_EINVAL;
+  CtxLock lk(cat->ctx);  // (kg_catalog_update_offerings moves the generation)
   if (n_types) *n_types = (uint32_t)cat->types.size();
   if (generation) *generation = cat->generation;
   return KG_OK;
