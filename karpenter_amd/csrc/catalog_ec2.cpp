@@ -62,28 +62,62 @@ bool scheme(const std::string& name, std::string* category, std::string* generat
   return false;
 }
 
-// resource.MustParse -> int64 milli (binary and decimal suffixes, decimals; finer than milli rounds up)
+// resource.MustParse -> int64 milli, in exact integer arithmetic: sign, digits, optional fraction, then a binary (Ki..Ei),
+// decimal (n u m k M G T P E) or exponent (e3 / E-3) suffix.  A value finer than one milli-unit is not representable in the
+// library's quantities: KG_EUNSUPPORTED (reject, do not round), as is one beyond int64.
 int64_t parse_quantity_milli(std::string_view s) {
+  using i128 = __int128;
   size_t i = 0;
-  while (i < s.size() && (s[i] == '.' || (s[i] >= '0' && s[i] <= '9') || s[i] == '-' || s[i] == '+')) ++i;
-  const std::string num(s.substr(0, i));
+  bool neg = false;
+  if (i < s.size() && (s[i] == '+' || s[i] == '-')) { neg = s[i] == '-'; ++i; }
+  i128 mant = 0;      // the digits, fraction included
+  int frac = 0;       // how many of them follow the point
+  bool any = false, point = false;
+  for (; i < s.size(); ++i) {
+    if (s[i] == '.' && !point) { point = true; continue; }
+    if (s[i] < '0' || s[i] > '9') break;
+    mant = mant * 10 + (s[i] - '0');
+    if (point) ++frac;
+    any = true;
+    if (mant > (i128)1 << 100) throw Unsupported("quantity with too many digits");
+  }
+  kgdesc::check(any, "empty quantity");
   const std::string suf(s.substr(i));
-  long double mult;
-  if (suf == "m") mult = 1;
-  else if (suf.empty()) mult = 1000;
-  else if (suf == "Ki") mult = 1000.0L * 1024;
-  else if (suf == "Mi") mult = 1000.0L * MI;
-  else if (suf == "Gi") mult = 1000.0L * GI;
-  else if (suf == "Ti") mult = 1000.0L * GI * 1024;
-  else if (suf == "k") mult = 1e6L;
-  else if (suf == "M") mult = 1e9L;
-  else if (suf == "G") mult = 1e12L;
-  else if (suf == "T") mult = 1e15L;
-  else throw Unsupported("quantity suffix not handled by the native catalog build");
-  kgdesc::check(!num.empty(), "empty quantity");
-  // exact for the integers and short decimals kubelet configuration uses
-  const long double v = std::stold(num) * mult;
-  return (int64_t)std::ceil((double)v - 1e-9);
+  i128 num = 1000, den = 1;  // value = mant / 10^frac * num / den milli-units
+  auto pow10 = [](int e) { i128 p = 1; for (int k = 0; k < e; ++k) p *= 10; return p; };
+  if (suf.empty()) {}
+  else if (suf == "n") den = pow10(9);
+  else if (suf == "u") den = pow10(6);
+  else if (suf == "m") num = 1;
+  else if (suf == "k") num = 1000 * pow10(3);
+  else if (suf == "M") num = 1000 * pow10(6);
+  else if (suf == "G") num = 1000 * pow10(9);
+  else if (suf == "T") num = 1000 * pow10(12);
+  else if (suf == "P") num = 1000 * pow10(15);
+  else if (suf == "E") num = 1000 * pow10(18);
+  else if (suf == "Ki") num = (i128)1000 << 10;
+  else if (suf == "Mi") num = (i128)1000 << 20;
+  else if (suf == "Gi") num = (i128)1000 << 30;
+  else if (suf == "Ti") num = (i128)1000 << 40;
+  else if (suf == "Pi") num = (i128)1000 << 50;
+  else if (suf == "Ei") num = (i128)1000 << 60;
+  else if ((suf[0] == 'e' || suf[0] == 'E') && suf.size() > 1) {
+    size_t k = 1;
+    bool eneg = false;
+    if (suf[k] == '+' || suf[k] == '-') { eneg = suf[k] == '-'; ++k; }
+    int e = 0;
+    kgdesc::check(k < suf.size(), "quantity exponent");
+    for (; k < suf.size(); ++k) { kgdesc::check(suf[k] >= '0' && suf[k] <= '9' && e < 100, "quantity exponent"); e = e * 10 + (suf[k] - '0'); }
+    if (e > 24) throw Unsupported("quantity exponent out of range");
+    if (eneg) den = pow10(e); else num = 1000 * pow10(e);
+  } else throw Unsupported("quantity suffix not handled by the native catalog build");
+  den *= pow10(frac > 30 ? 31 : frac);
+  if (frac > 30) throw Unsupported("quantity finer than one milli-unit");
+  const i128 scaled = mant * num;
+  if (scaled % den != 0) throw Unsupported("quantity finer than one milli-unit");
+  const i128 v = scaled / den;
+  if (v > (i128)INT64_MAX) throw Unsupported("quantity beyond int64 milli-units");
+  return neg ? -(int64_t)v : (int64_t)v;
 }
 
 // computeEvictionSignal (types.go:456-478)

@@ -1,5 +1,6 @@
 // device.hip -- gfx950 kernels and the HIP implementation of hal.hpp.
 #include <hip/hip_runtime.h>
+#include <rocprofiler-sdk-roctx/roctx.h>
 
 #include <mutex>
 #include <stdexcept>
@@ -53,65 +54,6 @@ __global__ void __launch_bounds__(NT) k_solve(DevProblem Pin, const SimState* si
   __shared__ Shared sh;
   const DevProblem& P = Pin;
   const SimState S = sims[blockIdx.x];
-  if (DBG && (P.stats & 2)) {
-    // micro-probes (debug timers only): cost of a bare barrier, of a dependent global load chain, of a flat LDS access
-    __shared__ uint32_t probe[64];
-    unsigned long long t0 = wall_clock64();
-    for (int i = 0; i < 1000; ++i) __syncthreads();
-    unsigned long long t1 = wall_clock64();
-    uint32_t idx = 0;
-    if (threadIdx.x == 0) for (int i = 0; i < 1000; ++i) idx = S.queue[(idx & 3) * 4] & 1;
-    __syncthreads();
-    unsigned long long t2 = wall_clock64();
-    for (int i = 0; i < 1000; ++i) { if (threadIdx.x == 0) probe[i & 63] = (uint32_t)i; __syncthreads(); idx += probe[(i + threadIdx.x) & 63]; __syncthreads(); }
-    unsigned long long t3 = wall_clock64();
-    for (int i = 0; i < 1000; ++i) { if (threadIdx.x == 0) S.scratch[i & 7] = i + idx; __syncthreads(); }
-    unsigned long long t4 = wall_clock64();
-    if (threadIdx.x == 0) { S.counters[26] = t1 - t0; S.counters[27] = t2 - t1; S.counters[28] = t3 - t2 + (idx & 1); S.counters[29] = t4 - t3; }
-    __syncthreads();
-    // latency of a dependent chain over 4096 lines (256 KiB: misses the 32 KiB L1): first walk = from HBM / MALL, second = L2;
-    // then a store -> load of the same line (what a phase sees of the previous phase's writes)
-    if ((size_t)(P.TW + 1) * P.Cmax * 8 >= 4096 * 64 && threadIdx.x == 0) {
-      for (uint32_t i = 0; i < 4096; ++i) S.scratch[(size_t)i * 8] = ((i * 1237u + 1u) & 4095u);  // i -> (1237 i + 1) mod 4096: one cycle
-      __threadfence();
-      uint64_t j = 0;
-      const unsigned long long a0 = wall_clock64();
-      for (int i = 0; i < 2048; ++i) j = S.scratch[j * 8];
-      const unsigned long long a1 = wall_clock64();
-      for (int i = 0; i < 2048; ++i) j = S.scratch[j * 8];
-      const unsigned long long a2 = wall_clock64();
-      uint64_t v = j;
-      for (int i = 0; i < 1000; ++i) { S.scratch[8] = v + 1; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); v = S.scratch[8]; }
-      const unsigned long long a3 = wall_clock64();
-      S.counters[60] = a1 - a0; S.counters[61] = a2 - a1; S.counters[62] = a3 - a2 + (v & 1); 
-      for (uint32_t i = 0; i < 4096; ++i) S.scratch[(size_t)i * 8] = 0;
-    }
-    __syncthreads();
-    // one round trip of 24 independent 8-byte loads per lane (the prefilter's shape: rows Cmax apart), 200 times:
-    // by one wave, by every wave, and the same with lanes scattered over the row
-    {
-      const size_t stride = (size_t)P.Cmax;
-      uint64_t acc = idx;
-      for (int variant = 0; variant < 3; ++variant) {
-        __syncthreads();
-        const unsigned long long b0 = wall_clock64();
-        const bool act = variant == 0 ? threadIdx.x < 64 : true;
-        const uint32_t lane = variant == 2 ? (threadIdx.x * 37u) % 311u : threadIdx.x % 311u;
-        if (act)
-          for (int it = 0; it < 200; ++it) {
-            uint64_t v[24];
-#pragma unroll
-            for (int k = 0; k < 24; ++k) v[k] = S.scratch[(size_t)(k % (P.TW + 1)) * stride + ((lane + (acc & 1)) % 311u)];
-#pragma unroll
-            for (int k = 0; k < 24; ++k) acc ^= v[k];
-          }
-        __syncthreads();
-        const unsigned long long b1 = wall_clock64();
-        if (threadIdx.x == 0) S.counters[56 + variant] = b1 - b0 + (acc == 77);
-      }
-    }
-    __syncthreads();
-  }
   const unsigned long long c0 = clock64(), w0 = wall_clock64();
   solve_block<NT, DBG>(P, S, sh, nqueue[blockIdx.x]);
   if (DBG && (P.stats & 2) && threadIdx.x == 0) { S.counters[24] = clock64() - c0; S.counters[25] = wall_clock64() - w0; }
@@ -244,7 +186,12 @@ void d2h(void* dst, const void* src, size_t bytes) {
 void dzero(void* dst, size_t bytes) { if (bytes) ck(hipMemsetAsync(dst, 0, bytes, t_stream), "hipMemset"); }
 void dfill(void* dst, int byte, size_t bytes) { if (bytes) ck(hipMemsetAsync(dst, byte, bytes, t_stream), "hipMemset"); }
 
-// HIP-event bracket of one launch group; the events come from the device's pool (created at kg_init) and go back to it
+// roctx ranges (rocprofv3 --marker-trace): every launch group and, from the host side, every entry point's phases
+void range_push(const char* name) { roctxRangePushA(name); }
+void range_pop() { roctxRangePop(); }
+
+// HIP-event bracket of one launch group; the events come from the device's pool (created at kg_init) and go back to it.
+// Doubles as the group's roctx range.
 struct Timer {
   hipEvent_t a, b;
   int dev = 0;
@@ -257,7 +204,8 @@ struct Timer {
     ck(hipEventCreate(&e), "event");
     return e;
   }
-  Timer() {
+  explicit Timer(const char* name) {
+    roctxRangePushA(name);
     ck(hipGetDevice(&dev), "hipGetDevice");
     a = take(dev); b = take(dev);
     ck(hipEventRecord(a, t_stream), "record");
@@ -267,6 +215,7 @@ struct Timer {
     ck(hipEventSynchronize(b), "kernel execution");
     float ms = 0;
     ck(hipEventElapsedTime(&ms, a, b), "elapsed");
+    roctxRangePop();
     std::lock_guard<std::mutex> lk(g_dev_mu);
     g_events[dev].push_back(a); g_events[dev].push_back(b);
     return ms;
@@ -274,7 +223,7 @@ struct Timer {
 };
 
 void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms) {
-  Timer t;
+  Timer t("kg prepass (k_type_filter, k_node_static, k_pod_mask, k_pod_ctx)");
   const uint32_t total = X.E * (uint32_t)P.TW;
   if (total) hipLaunchKernelGGL(k_type_filter, dim3((total + 255) / 256), dim3(256), 0, t_stream, P, X);
   if (P.N > 0 && P.S > 0) hipLaunchKernelGGL(k_node_static, dim3((P.N + 255) / 256, P.S), dim3(256), 0, t_stream, P, X);
@@ -287,7 +236,7 @@ void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms) {
 }
 
 void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int block, float* ms, bool batch) {
-  Timer t;
+  Timer t("kg solve (k_solve / k_simulate)");
   if (batch) {
     if (block >= 512) hipLaunchKernelGGL((k_simulate<512>), dim3(nsims), dim3(512), 0, t_stream, P, sims, nqueue);
     else hipLaunchKernelGGL((k_simulate<256>), dim3(nsims), dim3(256), 0, t_stream, P, sims, nqueue);
@@ -295,6 +244,7 @@ void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const ui
     *ms = t.stop();
     return;
   }
+  if (P.stats & 2) launch_probes(P, sims, t_stream);  // (debug_probes.hip)
   if (P.stats & (2 | 8)) hipLaunchKernelGGL((k_solve<256, true>), dim3(nsims), dim3(256), 0, t_stream, P, sims, nqueue);  // debug timers: 256 threads only
   else if (block >= 1024) hipLaunchKernelGGL((k_solve<1024, false>), dim3(nsims), dim3(1024), 0, t_stream, P, sims, nqueue);
   else if (block >= 512) hipLaunchKernelGGL((k_solve<512, false>), dim3(nsims), dim3(512), 0, t_stream, P, sims, nqueue);
@@ -303,20 +253,20 @@ void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const ui
   *ms = t.stop();
 }
 void launch_solve_wave(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, float* ms) {
-  Timer t;
+  Timer t("kg solve (k_solve_wave)");
   if (P.stats & 8) hipLaunchKernelGGL((k_solve_wave<true>), dim3(nsims), dim3(64), 0, t_stream, P, sims, nqueue);
   else hipLaunchKernelGGL((k_solve_wave<false>), dim3(nsims), dim3(64), 0, t_stream, P, sims, nqueue);
   ck(hipGetLastError(), "solve (wave) launch");
   *ms = t.stop();
 }
 void launch_sim_init(const DevProblem& P, const SimBatch& B, float* ms) {
-  Timer t;
+  Timer t("kg k_sim_init");
   if (B.nsims) hipLaunchKernelGGL(k_sim_init, dim3(B.nsims), dim3(256), 0, t_stream, P, B);
   ck(hipGetLastError(), "sim init launch");
   *ms = t.stop();
 }
 void launch_sim_gather(const DevProblem& P, const SimBatch& B, const SimState* sims, float* ms) {
-  Timer t;
+  Timer t("kg k_sim_gather");
   if (B.nsims) hipLaunchKernelGGL(k_sim_gather, dim3((B.nsims + 63) / 64), dim3(64), 0, t_stream, P, B, sims);
   ck(hipGetLastError(), "sim gather launch");
   *ms = t.stop();

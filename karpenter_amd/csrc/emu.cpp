@@ -68,5 +68,8 @@ void launch_sim_gather(const DevProblem& P, const SimBatch& B, const SimState* s
   for (int i = 0; i < B.nsims; ++i) sim_gather(P, B, sims[i], (uint32_t)i);
   *ms = 0;
 }
+void launch_probes(const DevProblem&, const SimState*, void*) {}
+void range_push(const char*) {}
+void range_pop() {}
 const char* backend() { return "emu"; }
 }  // namespace kg::hal

@@ -34,5 +34,14 @@ void launch_solve_wave(const DevProblem& P, const SimState* sims, int nsims, con
 // consolidation batches: k_sim_init (state slots from the pristine image + per-simulation patches), k_sim_gather
 void launch_sim_init(const DevProblem& P, const SimBatch& B, float* ms);
 void launch_sim_gather(const DevProblem& P, const SimBatch& B, const SimState* sims, float* ms);
+// debug_probes.hip: the latency micro-probes (debug timers only)
+void launch_probes(const DevProblem& P, const SimState* sims, void* stream);
+// roctx ranges around the host phases of an entry point (the launch groups above carry their own)
+void range_push(const char* name);
+void range_pop();
+struct Range {
+  explicit Range(const char* name) { range_push(name); }
+  ~Range() { range_pop(); }
+};
 const char* backend();
 }  // namespace kg::hal

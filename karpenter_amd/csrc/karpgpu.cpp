@@ -1801,6 +1801,8 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
                           const kg_nodepools_desc* nodepools, kg_results* out, bool add_pods_one, FixedArena* fixed) {
   {
   auto t0 = std::chrono::steady_clock::now();
+  std::optional<hal::Range> phase;  // (roctx: rocprofv3 --marker-trace shows the host phases next to the launch groups)
+  phase.emplace("kg_solve: host compile");
   ParsedPods pending;
   parse_pods(ctx, pods, &pending, add_pods_one);
   check(out->cap_pods >= pending.pods.size(), "pod result capacity");
@@ -1808,6 +1810,7 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
   in.fixed = fixed;
   const bool stats = ctx->collect_stats;
   auto C = compile_problem(in, stats);
+  phase.reset();
   auto t1 = std::chrono::steady_clock::now();
   float ms_pre = 0, ms_solve = 0;
   hal::launch_prepass(C->dp, C->pre, &ms_pre);
@@ -1817,6 +1820,7 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
   else hal::launch_solve(C->dp, (const SimState*)C->sims_dev.ptr, 1, nq_dev, ctx->block_threads, &ms_solve);
   ctx->stats.kernel_launches += 3;
   // ---- results
+  phase.emplace("kg_solve: decode");
   const int P = C->P, Cmax = C->Cmax, TW = C->TW, R = C->R, Ka = C->Ka;
   std::vector<uint8_t> pod_kind(std::max(P, 1));
   std::vector<int32_t> pod_index(std::max(P, 1));
@@ -2338,6 +2342,8 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   *n_records = 0;
   if (device_ms) *device_ms = 0;
   HostProf prof_;
+  std::optional<hal::Range> phase;
+  phase.emplace("kg_consolidate: plan");
   KG_PROF("cons: plan lookup");
   // ---- the plan: found by the content of what it was built from, or built now
   kg_cons_plan* PLp = nullptr;
@@ -2423,6 +2429,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   const std::vector<uint32_t>& live = PL.live;
   if (live.empty()) return KG_OK;
 
+  phase.reset();
   KG_PROF("cons: kernels");
   double ms_total = PL.ms_prepass, ms_init = 0, ms_sim = 0, ms_gather = 0;
   const float ms_pre = PL.ms_prepass;
@@ -2494,6 +2501,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
     }
     return KG_OK;
   }
+  phase.emplace("kg_consolidate: decisions");
   KG_PROF("cons: decisions");
   // ---- computeConsolidation's decision logic per simulation (prices are float64 catalog data: host side)
   // (records[] is indexed by position in `mine`; live[li] is a unit index)

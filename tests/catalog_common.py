@@ -45,12 +45,22 @@ def check_ec2_build(L):
         dict(base, ami_family="AL2", max_pods=58, kube_reserved={"cpu": "250m", "memory": "1Gi"}, system_reserved={"memory": "200Mi"},
              eviction_hard={"memory.available": "5%", "nodefs.available": "15%"}, eviction_soft={"memory.available": "750Mi"}),
         dict(base, ami_family="Windows2022", pods_per_core=4),
+        # quantities with fractions and exponents (parsed exactly), still whole milli-units
+        dict(base, ami_family="AL2", eviction_hard={"memory.available": "1e9", "nodefs.available": "10%"}, eviction_soft={"memory.available": "1.5Gi", "nodefs.available": "100.5Mi"}),
         dict(base, ami_family="AL2023", instance_store_policy="RAID0", unavailable={("spot", infos[0]["InstanceType"], zones[0]), ("on-demand", infos[9]["InstanceType"], zones[2])}),
     ]
     # the single-valued labels of the 776 documented rows (AL2023, the doc generator's node class = variant 0)
     doc = {r["name"]: {k: v for k, v in r["labels"].items() if k != "karpenter.k8s.aws/instance-network-bandwidth" or True} for r in wl._load("instance_types_doc.json")}
     for vi, ctx in enumerate(variants):
         types = _check_tables(L, infos, ctx, oz, doc if vi == 0 else None)
+    # a quantity finer than one milli-unit is not representable: refused, not rounded
+    for bad in ("0.0001", "1.0000001Mi", "5u"):
+        ctx = dict(base, eviction_hard={"memory.available": bad})
+        try:
+            L.dll.kg_catalog_free(L.catalog_build_ec2(abi.build_ec2_catalog(infos[:4], ctx, ctx["limits"], ctx["bandwidth"], oz)))
+            raise AssertionError("expected KG_EUNSUPPORTED for %r" % bad)
+        except Exception as e:  # noqa: BLE001
+            assert "EUNSUPPORTED" in str(e) and "milli" in str(e), (bad, e)
     # behaviour: a Solve over the natively built catalog == a Solve over the uploaded oracle catalog
     ctx = variants[-1]
     types = co.list_instance_types(infos, ctx, ctx["limits"], ctx["bandwidth"], oz)
