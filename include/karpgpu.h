@@ -224,6 +224,10 @@ typedef struct {
   int32_t deletion_cost;
   int32_t node;                 /* bound pods: index into cluster nodes; -1 for pending pods */
   uint8_t reschedulable;        /* bound pods: counted in candidate.reschedulablePods */
+  kg_range volumes;             /* pools.labels: (CSI driver, volume id) of every PVC-backed volume the pod mounts -- what
+                                   ExistingNode.Add checks against the node's volume limits.  A volume
+                                   named by two pods of one call, or already in use on a node by another pod, makes the count
+                                   a set union the device path does not model: KG_EUNSUPPORTED, the caller keeps its CPU path */
 } kg_pod;
 
 typedef struct {
@@ -245,6 +249,8 @@ typedef struct {
   kg_range daemon_requests; /* remaining daemonset requests, already clamped >= 0 */
   uint8_t initialized, managed, deleting;
   double price;             /* unused on input; reserved */
+  kg_range volume_limits;   /* pools.quantities: CSI driver -> attachable volume count x 1000 (CSINode allocatable); drivers not
+                               listed are unlimited.  Volumes in use = those of the pods bound to the node */
 } kg_node;
 
 typedef struct {

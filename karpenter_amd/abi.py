@@ -36,9 +36,10 @@ POD = np.dtype([("uid", "<u4"), ("ns", "<u4"), ("creation_ts", "<i8"), ("labels"
                 ("required_terms", RANGE), ("preferred_terms", RANGE), ("tolerations", RANGE), ("spreads", RANGE),
                 ("affinity_required", RANGE), ("affinity_preferred", RANGE), ("anti_affinity_required", RANGE),
                 ("anti_affinity_preferred", RANGE), ("host_ports", RANGE), ("priority", "<i4"), ("deletion_cost", "<i4"),
-                ("node", "<i4"), ("reschedulable", "u1")], align=True)
+                ("node", "<i4"), ("reschedulable", "u1"), ("volumes", RANGE)], align=True)
 NODE = np.dtype([("name", "<u4"), ("labels", RANGE), ("taints", RANGE), ("available", RANGE), ("capacity", RANGE),
-                 ("daemon_requests", RANGE), ("initialized", "u1"), ("managed", "u1"), ("deleting", "u1"), ("price", "<f8")], align=True)
+                 ("daemon_requests", RANGE), ("initialized", "u1"), ("managed", "u1"), ("deleting", "u1"), ("price", "<f8"),
+                 ("volume_limits", RANGE)], align=True)
 NODEPOOL = np.dtype([("name", "<u4"), ("weight", "<i4"), ("requirements", RANGE), ("labels", RANGE), ("taints", RANGE),
                      ("has_limits", "u1"), ("limits", RANGE), ("daemon_overhead", RANGE), ("catalog", "<u4"),
                      ("catalog_generation", "<u8")], align=True)
@@ -209,6 +210,13 @@ class _PoolBuilder:
             self.labels.append((self.s(k), self.s(str(v))))
         return (b, len(self.labels) - b)
 
+    def pair_list(self, pairs):
+        """(key, value) pairs, repeats allowed (a pod's (CSI driver, volume id) list)."""
+        b = len(self.labels)
+        for k, v in pairs or ():
+            self.labels.append((self.s(k), self.s(str(v))))
+        return (b, len(self.labels) - b)
+
     def taint_list(self, ts):
         b = len(self.taints)
         for k, v, e in ts or ():
@@ -318,7 +326,7 @@ def _fill_pods(pb, pods):
                      terms(p.get("affinity_required")), terms(p.get("affinity_preferred")),
                      terms(p.get("anti_affinity_required")), terms(p.get("anti_affinity_preferred")),
                      (hb, len(hports) - hb), int(p.get("priority", 0)), int(p.get("deletion_cost", 0)),
-                     int(p.get("node", -1)), 1 if p.get("reschedulable", True) else 0))
+                     int(p.get("node", -1)), 1 if p.get("reschedulable", True) else 0, pb.pair_list(p.get("volumes"))))
     arrs = dict(pods=np.array(rows, dtype=POD) if rows else np.zeros(0, POD),
                 weighted_terms=np.array(wterms, dtype=WEIGHTED_TERM) if wterms else np.zeros(0, WEIGHTED_TERM),
                 spreads=np.array(spreads, dtype=SPREAD) if spreads else np.zeros(0, SPREAD),
@@ -350,7 +358,8 @@ def build_cluster(nodes, bound_pods):
         rows.append((pb.s(n["name"]), pb.label_list(n.get("labels")), pb.taint_list(n.get("taints")),
                      pb.quantity_list(n.get("available")), pb.quantity_list(n.get("capacity")),
                      pb.quantity_list(n.get("daemon_requests")), 1 if n.get("initialized", True) else 0,
-                     1 if n.get("managed", True) else 0, 1 if n.get("deleting", False) else 0, 0.0))
+                     1 if n.get("managed", True) else 0, 1 if n.get("deleting", False) else 0, 0.0,
+                     pb.quantity_list({k: int(v) * 1000 for k, v in (n.get("volume_limits") or {}).items()})))
     nodes_a = np.array(rows, dtype=NODE) if rows else np.zeros(0, NODE)
     d = ClusterDesc()
     d.pods = _pods_desc(pb, arrs)

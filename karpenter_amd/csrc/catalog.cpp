@@ -79,6 +79,8 @@ void build_catalog_tables(kg_ctx* ctx, kg_catalog* cat) {
       // resources.Subtract(Capacity, Overhead.Total()): only keys of Capacity appear in Allocatable
       for (auto& ck : cat->types[t].capacity) if (ck.first == kv.first) alloc[(size_t)kv.first * T + t] -= kv.second;
   }
+  for (uint32_t r = 0; r < R; ++r)
+    if (is_volume_resource(V.resources.strs[r])) for (uint32_t t = 0; t < T; ++t) alloc[(size_t)r * T + t] = INT64_MAX / 4;  // (volume limits belong to registered nodes: a NodeClaim has none)
   std::vector<uint64_t> valid(tw, 0);
   for (uint32_t t = 0; t < T; ++t) {
     bool ok = true;

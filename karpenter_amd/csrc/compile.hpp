@@ -54,7 +54,12 @@ struct ParsedPods {
   std::vector<PodClass> classes;
   std::vector<PodRef> pods;
   std::vector<std::pair<uint32_t, int64_t>> rq;  // (resource id, milli) pairs of every pod's requests
+  // volumes (ExistingNode.Add's volume limits): the pods' volume ids, sorted; a pod's count per CSI driver rides in `rq` as a
+  // request of the internal resource "karpgpu.internal/volumes/<driver>" (additive as long as no volume is shared)
+  std::vector<uint32_t> vols;
+  bool vols_shared = false;  // two pods of this set name the same volume
 };
+
 
 void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out, bool add_pods_one);
 
@@ -65,6 +70,7 @@ struct CNode {
   std::vector<std::pair<uint32_t, int64_t>> available, capacity, daemon;
   bool initialized, managed, deleting;
   uint32_t hostname_val;  // value id under the hostname key
+  std::vector<uint32_t> volume_limited;  // internal volume resources this node has a limit for (its `available` carries what is left)
 };
 
 }  // namespace kg

@@ -27,6 +27,9 @@ namespace kg {
 struct Unsupported : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
+// the internal resource a CSI driver's volume count rides on (compile.hpp: ParsedPods::vols)
+inline const char* kVolumeResourcePrefix() { return "karpgpu.internal/volumes/"; }
+inline bool is_volume_resource(const std::string& name) { return name.rfind(kVolumeResourcePrefix(), 0) == 0; }
 struct Stale : std::runtime_error {  // -> KG_ESTALE
   using std::runtime_error::runtime_error;
 };

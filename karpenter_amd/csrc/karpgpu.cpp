@@ -169,6 +169,17 @@ void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out, bool add_po
       for (auto& kv : rl) if (kv.first == ctx->rPods) { kv.second += 1000; found = true; }
       if (!found) { rl.push_back({ctx->rPods, 1000}); std::sort(rl.begin(), rl.end()); }
     }
+    if (q.volumes.count) {  // volumes per CSI driver -> requests of the driver's internal resource
+      for (auto& l : kgdesc::labels(p, q.volumes)) {
+        const std::string drv(kgdesc::str(p.strings, l.key));
+        const uint32_t rid = ctx->V.resources.id(kVolumeResourcePrefix() + drv);
+        bool found = false;
+        for (auto& kv : rl) if (kv.first == rid) { kv.second += 1000; found = true; }
+        if (!found) rl.push_back({rid, 1000});
+        out->vols.push_back(ctx->lab.id(drv + "\x1f" + std::string(kgdesc::str(p.strings, l.value))));
+      }
+      std::sort(rl.begin(), rl.end());
+    }
     pr.rq_off = (uint32_t)out->rq.size(); pr.rq_n = (uint32_t)rl.size();
     out->rq.insert(out->rq.end(), rl.begin(), rl.end());
     pr.uid = std::string(kgdesc::str(p.strings, q.uid));
@@ -179,6 +190,19 @@ void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out, bool add_po
     pr.deletion_cost = q.deletion_cost;
     out->pods.push_back(std::move(pr));
   }
+  std::sort(out->vols.begin(), out->vols.end());
+  out->vols_shared = std::adjacent_find(out->vols.begin(), out->vols.end()) != out->vols.end();
+}
+
+// Volume counts are modelled as additive requests; that is exact as long as every volume belongs to one pod of the call.
+static void check_volumes_unshared(const ParsedPods& pending, const kg_cluster* cluster) {
+  bool shared = pending.vols_shared || (cluster && cluster->bound.vols_shared);
+  if (!shared && cluster && !pending.vols.empty()) {
+    const auto& a = pending.vols;
+    const auto& b = cluster->bound.vols;
+    for (size_t i = 0, j = 0; i < a.size() && j < b.size() && !shared;) { if (a[i] == b[j]) shared = true; else if (a[i] < b[j]) ++i; else ++j; }
+  }
+  if (shared) throw Unsupported("a volume is mounted by more than one pod of this call (volume-limit counts become set unions): not on the device path");
 }
 
 // ------------------------------------------------------------------ compile
@@ -1011,12 +1035,15 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
 
   KG_PROF("nodes -> device rows");
   // ---- nodes -> device rows
+  std::vector<uint8_t> vol_res(std::max(R, 1), 0);
+  for (int r = 0; r < R; ++r) vol_res[r] = is_volume_resource(V.resources.strs[C.act_res[r]]);
   std::vector<int64_t> navail((size_t)std::max(R, 1) * std::max(N, 1), 0), nreq0(navail.size(), 0);
   std::vector<uint16_t> nval((size_t)std::max(Ka, 1) * std::max(N, 1), 0xFFFF), ndom((size_t)std::max(nspec, 1) * std::max(N, 1), 0xFFFF);
   std::vector<uint64_t> ntol((size_t)TS * NW, 0);
   for (int n = 0; n < N; ++n) {
     const CNode& nd = *nodes[n];
     bool valid = true;
+    for (int r = 0; r < R; ++r) if (vol_res[r]) navail[(size_t)r * N + n] = INT64_MAX / 4;  // (no CSINode limit for the driver: unlimited)
     for (auto& kv : nd.available) { if (ract[kv.first] >= 0) navail[(size_t)ract[kv.first] * N + n] = kv.second; if (kv.second < 0) valid = false; }
     for (auto& kv : nd.daemon) {
       if (ract[kv.first] >= 0) nreq0[(size_t)ract[kv.first] * N + n] = kv.second;
@@ -1716,6 +1743,20 @@ int32_t kg_cluster_upload(kg_ctx* ctx, const kg_cluster_desc* desc, kg_cluster**
   }
   parse_pods(ctx, &desc->pods, &cl->bound, true);
   for (auto& bp : cl->bound.pods) check(bp.node >= 0 && bp.node < (int)cl->nodes.size(), "bound pod node index");
+  // volume limits: what the node can still attach per CSI driver = CSINode count - volumes of the pods bound to it (clamped at
+  // 0: a node over its limit takes no more volumes but still takes pods without any)
+  for (uint32_t i = 0; i < desc->n_nodes; ++i) {
+    if (desc->nodes[i].volume_limits.count == 0) continue;
+    for (auto& q : kgdesc::quantities(p, desc->nodes[i].volume_limits)) {
+      const uint32_t rid = V.resources.id(kVolumeResourcePrefix() + std::string(kgdesc::str(p.strings, q.name)));
+      int64_t left = q.milli;
+      for (auto& bp : cl->bound.pods)
+        if (bp.node == (int)i)
+          for (uint32_t k = 0; k < bp.rq_n; ++k) if (cl->bound.rq[bp.rq_off + k].first == rid) left -= cl->bound.rq[bp.rq_off + k].second;
+      cl->nodes[i].available.push_back({rid, std::max<int64_t>(left, 0)});
+      cl->nodes[i].volume_limited.push_back(rid);
+    }
+  }
   *out = cl.release();
   return KG_OK;
   KG_GUARD_END(ctx)
@@ -1806,6 +1847,7 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
   ParsedPods pending;
   parse_pods(ctx, pods, &pending, add_pods_one);
   check(out->cap_pods >= pending.pods.size(), "pod result capacity");
+  check_volumes_unshared(pending, cluster);
   SolveInputs in{ctx, catalogs[0], cluster, nodepools, &pending};
   in.fixed = fixed;
   const bool stats = ctx->collect_stats;
@@ -1976,7 +2018,8 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
     co.requirements.count = (uint32_t)tmp.size();
     for (auto& q : tmp) W.add_req(q);
     std::vector<std::pair<std::string, int64_t>> rq;
-    for (int r = 0; r < R; ++r) if (c_req[(size_t)r * nclaims + c] != 0) rq.push_back({V.resources.strs[C->act_res[r]], c_req[(size_t)r * nclaims + c]});
+    for (int r = 0; r < R; ++r)
+      if (c_req[(size_t)r * nclaims + c] != 0 && !is_volume_resource(V.resources.strs[C->act_res[r]])) rq.push_back({V.resources.strs[C->act_res[r]], c_req[(size_t)r * nclaims + c]});
     std::sort(rq.begin(), rq.end());
     co.requests.begin = out->needed_quantities;
     co.requests.count = (uint32_t)rq.size();
@@ -2147,6 +2190,7 @@ static std::unique_ptr<kg_cons_plan> build_cons_plan(kg_ctx* ctx, kg_catalog* ca
   // ---- pod universe: pending pods, pods of deleting nodes, then the candidates' reschedulable pods in candidate order
   ParsedPods pend;
   parse_pods(ctx, pending, &pend, true);
+  check_volumes_unshared(pend, cluster);
   ParsedPods U;
   U.classes = pend.classes;
   const uint32_t cls_off = (uint32_t)U.classes.size();

@@ -340,6 +340,7 @@ struct Pod {
   vector<Spread> spreads;
   vector<AffTerm> affReq, affPref, antiReq, antiPref;
   vector<HostPort> hostPorts;
+  std::map<int, std::set<int>> volumes;  // CSI driver -> ids of the PVC-backed volumes the pod mounts
   int priority = 0, deletionCost = 0, node = -1;
   bool reschedulable = true;
 };
@@ -403,6 +404,7 @@ static vector<std::unique_ptr<Pod>> parsePods(Intern& in, const kg_pods_desc* d,
     pod->antiPref = parseTerms(P, d, q.anti_affinity_preferred);
     for (auto& h : kgdesc::span(d->host_ports, d->n_host_ports, q.host_ports, "host port range"))
       pod->hostPorts.push_back({h.ip == KG_NONE ? -1 : P.sid(p, h.ip), h.port, h.protocol});
+    for (auto& l : kgdesc::labels(p, q.volumes)) pod->volumes[P.sid(p, l.key)].insert(P.sid(p, l.value));
     pod->priority = q.priority;
     pod->deletionCost = q.deletion_cost;
     pod->node = q.node;
@@ -786,6 +788,21 @@ struct ExistingNode {
   Requirements requirements;
   vector<Pod*> pods;
   HostPortUsage hostPorts;
+  // scheduling.VolumeUsage: volumes in use per CSI driver, and the CSINode's attachable count (drivers without one: unlimited)
+  std::map<int, std::set<int>> volumes;
+  std::map<int, int64_t> volumeLimits;
+  bool ExceedsLimits(const Pod& pod) const {
+    for (auto& kv : pod.volumes) {
+      auto lim = volumeLimits.find(kv.first);
+      if (lim == volumeLimits.end()) continue;
+      std::set<int> u = kv.second;
+      auto have = volumes.find(kv.first);
+      if (have != volumes.end()) u.insert(have->second.begin(), have->second.end());
+      if ((int64_t)u.size() > lim->second) return true;
+    }
+    return false;
+  }
+  void AddVolumes(const Pod& pod) { for (auto& kv : pod.volumes) volumes[kv.first].insert(kv.second.begin(), kv.second.end()); }
 };
 
 static vector<InstanceType*> filterInstanceTypesByRequirements(const vector<InstanceType*>& its, const Requirements& reqs, const RL& requests,
@@ -907,6 +924,7 @@ struct Scheduler {
   // ExistingNode.Add
   bool nodeAdd(ExistingNode& n, Pod& pod, uint32_t* reason) {
     if (!Tolerates(n.taints, pod)) { *reason |= KG_REASON_TAINTS; return false; }
+    if (n.ExceedsLimits(pod)) { *reason |= KG_REASON_RESOURCES; return false; }  // "would exceed node volume limits"
     if (n.hostPorts.Conflicts(pod)) { *reason |= KG_REASON_REQUIREMENTS; return false; }
     RL requests = Merge(n.requests, pod.requests);
     if (!Fits(requests, n.available)) { *reason |= KG_REASON_RESOURCES; return false; }
@@ -924,6 +942,7 @@ struct Scheduler {
     n.requirements = std::move(nodeReqs);
     topo.Record(pod, n.requirements, nullptr);
     n.hostPorts.Add(pod);
+    n.AddVolumes(pod);
     return true;
   }
   // Scheduler.add
@@ -1066,6 +1085,7 @@ struct Problem {
     RL available, capacity, daemonRequests;
     bool initialized, managed, deleting;
     vector<Pod*> pods;
+    std::map<int, int64_t> volumeLimits;
   };
   vector<CNode> nodes;
   vector<NodeView> nodeViews;
@@ -1135,6 +1155,7 @@ static std::unique_ptr<Problem> buildProblem(const kg_catalog_desc* const* catal
       cn.initialized = n.initialized;
       cn.managed = n.managed;
       cn.deleting = n.deleting;
+      for (auto& q : kgdesc::quantities(cp, n.volume_limits)) cn.volumeLimits[P.sid(cp, q.name)] = q.milli / 1000;
       pr->nodes.push_back(std::move(cn));
     }
     for (auto& bp : pr->bound) {
@@ -1191,7 +1212,8 @@ static std::unique_ptr<Scheduler> newScheduler(Problem& pr, const vector<Pod*>& 
     int hostname = cn.labels.count(C.keyHostname) ? cn.labels[C.keyHostname] : cn.name;
     en->requirements.Add(Requirement::New(C.keyHostname, In, {hostname}));
     s->topo.Register(C.keyHostname, hostname);
-    for (Pod* bp : cn.pods) en->hostPorts.Add(*bp);
+    for (Pod* bp : cn.pods) { en->hostPorts.Add(*bp); en->AddVolumes(*bp); }
+    en->volumeLimits = cn.volumeLimits;
     auto npl = cn.labels.find(C.keyNodePool);
     if (npl != cn.labels.end()) {
       for (auto& np : pr.pools) {

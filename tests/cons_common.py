@@ -47,6 +47,19 @@ def cluster(name, n):
         from tests.helpers import _with_host_ports
         nodes, bound = wl.dense_cluster(n, 19, types, zones, lo=0.4, hi=0.9)
         return types, nodes, _with_host_ports(bound, 8), []
+    if name == "volumes":
+        # every bound pod of a third of the apps holds an EBS volume; nodes carry CSINode counts that leave room for 0..3 more:
+        # a candidate's pods can only move where their volumes still attach (or to a replacement)
+        nodes, bound = wl.dense_cluster(n, 29, types, zones, lo=0.3, hi=0.8)
+        per_node = {}
+        for i, p in enumerate(bound):
+            if int(p["labels"]["app"][-2:]) % 3 == 0:
+                p["volumes"] = [("ebs.csi.aws.com", "vol-%05d" % i)]
+                per_node[p["node"]] = per_node.get(p["node"], 0) + 1
+        for i, nd in enumerate(nodes):
+            if i % 5 != 4:
+                nd["volume_limits"] = {"ebs.csi.aws.com": per_node.get(i, 0) + i % 4}
+        return types, nodes, bound, []
     raise KeyError(name)
 
 

@@ -91,7 +91,7 @@ class Problem:
 
     def __init__(self, types, pods, nodepools, nodes=None, bound=None, max_instance_types=60):
         self.types = types
-        self.raw_pods, self.raw_nodes = pods, nodes  # (kept for property checks)
+        self.raw_pods, self.raw_nodes, self.raw_bound, self.raw_nodepools = pods, nodes, bound, nodepools  # (kept for property checks / variations)
         self.n_pods = len(pods)
         self.cat = abi.build_catalog(types)
         self.pods = abi.build_pods(pods)
@@ -126,7 +126,7 @@ def c5_nodepools():
 # parity scenarios for the scheduler features beyond the BASELINE shapes (Preferences.Relax steps, minDomains, daemon
 # overhead, node taints / tolerations, capacity-type spread, pod affinity, OR-ed node-affinity terms, negative operators)
 FEATURE_SCENARIOS = ["schedule_anyway", "prefer_no_schedule", "preferred_pod_affinity", "min_domains", "daemon_overhead", "node_taints",
-                     "ct_spread", "pod_affinity", "two_required_terms", "negative_selectors", "relax_everything"]
+                     "ct_spread", "pod_affinity", "two_required_terms", "negative_selectors", "relax_everything", "volume_limits"]
 
 
 def _pod(uid, cpu, mem_gi, app, ts=1700000000, **kw):
@@ -235,6 +235,25 @@ def feature_scenario(name):
         tainted = wl.default_nodepool("tainted", weight=10)
         tainted["taints"] = [("dedicated", "batch", "NoSchedule")]
         return Problem(types, pods, [tainted, wl.default_nodepool()], nodes=nodes, bound=bound)
+    if name == "volume_limits":
+        # ExistingNode.Add's volume limits (Appendix A.5): nodes with a CSINode count per driver, bound pods already holding
+        # volumes (some nodes full, one over its limit), pending pods with 0..3 volumes of two drivers; nodes without a limit
+        # for a driver take any number; NodeClaims have no limit
+        nodes, bound = wl.existing_cluster(120, 51, types, zones, util=0.2)
+        EBS, EFS = "ebs.csi.aws.com", "efs.csi.aws.com"
+        for i, nd in enumerate(nodes):
+            if i % 4 != 3:
+                nd["volume_limits"] = {EBS: [1, 2, 4, 25][i % 4]}
+            if i % 5 == 0:
+                nd["volume_limits"] = dict(nd.get("volume_limits") or {}, **{EFS: 1})
+        for i, p in enumerate(bound):
+            if i % 3 == 0:
+                p["volumes"] = [(EBS, "vol-bound-%05d" % i)] + ([(EBS, "vol-bound-%05d-b" % i)] if i % 9 == 0 else [])
+        pods = wl.mixed_pods(500, 53, zones, fams)
+        for i, p in enumerate(pods):
+            k = i % 4
+            p["volumes"] = [(EBS, "vol-%04d-%d" % (i, j)) for j in range(k)] + ([(EFS, "fs-%04d" % i)] if i % 7 == 0 else [])
+        return Problem(types, pods, [wl.default_nodepool()], nodes=nodes, bound=bound)
     if name == "ct_spread":
         # topology spread over capacity types (scheduling.md:370-373), alone and together with a zone spread
         pods = []

@@ -249,3 +249,8 @@ def test_multi_catalog_consolidation(L):
 def test_stale_catalog_generation(L):
     from tests.multicat_common import check_stale_generation
     check_stale_generation(L)
+
+
+def test_volume_limits(L):
+    from tests.volume_common import check_volume_limits
+    check_volume_limits(L)
