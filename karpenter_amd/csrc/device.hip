@@ -183,6 +183,11 @@ void d2h(void* dst, const void* src, size_t bytes) {
   ck(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, t_stream), "hipMemcpy D2H");
   ck(hipStreamSynchronize(t_stream), "hipMemcpy D2H");
 }
+void d2h_rows(void* dst, const void* src, size_t width, size_t spitch, size_t rows) {
+  if (!width || !rows) return;
+  ck(hipMemcpy2DAsync(dst, width, src, spitch, width, rows, hipMemcpyDeviceToHost, t_stream), "hipMemcpy2D D2H");
+  ck(hipStreamSynchronize(t_stream), "hipMemcpy2D D2H");
+}
 void dzero(void* dst, size_t bytes) { if (bytes) ck(hipMemsetAsync(dst, 0, bytes, t_stream), "hipMemset"); }
 void dfill(void* dst, int byte, size_t bytes) { if (bytes) ck(hipMemsetAsync(dst, byte, bytes, t_stream), "hipMemset"); }
 

@@ -23,6 +23,9 @@ void* dmalloc(size_t bytes) { return std::calloc(bytes ? bytes : 8, 1); }
 void dfree(void* p) { std::free(p); }
 void h2d(void* dst, const void* src, size_t bytes) { if (bytes) std::memcpy(dst, src, bytes); }
 void d2h(void* dst, const void* src, size_t bytes) { if (bytes) std::memcpy(dst, src, bytes); }
+void d2h_rows(void* dst, const void* src, size_t width, size_t spitch, size_t rows) {
+  for (size_t r = 0; r < rows; ++r) std::memcpy((char*)dst + r * width, (const char*)src + r * spitch, width);
+}
 void dzero(void* dst, size_t bytes) { if (bytes) std::memset(dst, 0, bytes); }
 void dfill(void* dst, int byte, size_t bytes) { if (bytes) std::memset(dst, byte, bytes); }
 

@@ -23,6 +23,8 @@ void* dmalloc(size_t bytes);
 void dfree(void* p);
 void h2d(void* dst, const void* src, size_t bytes);
 void d2h(void* dst, const void* src, size_t bytes);
+// `rows` rows of `width` bytes, `spitch` bytes apart on the device, packed back to back on the host: one strided copy
+void d2h_rows(void* dst, const void* src, size_t width, size_t spitch, size_t rows);
 void dzero(void* dst, size_t bytes);
 void dfill(void* dst, int byte, size_t bytes);  // debugging aid (KG_POISON): device memory filled with a byte pattern
 // k_type_filter + k_node_static + k_pod_mask

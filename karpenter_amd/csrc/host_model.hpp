@@ -10,6 +10,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -35,10 +36,17 @@ struct Stale : std::runtime_error {  // -> KG_ESTALE
 };
 
 struct StrMap {
-  std::vector<std::string> strs;
-  std::unordered_map<std::string, uint32_t> ids;
+  std::deque<std::string> strs;  // (a deque: the strings never move, so the index below can key on views of them and a lookup
+                                 //  builds no temporary std::string)
+  std::unordered_map<std::string_view, uint32_t> ids;
+  StrMap() = default;
+  StrMap(const StrMap& o) : strs(o.strs) { for (uint32_t i = 0; i < strs.size(); ++i) ids.emplace(strs[i], i); }
+  StrMap& operator=(const StrMap& o) {
+    if (this != &o) { strs = o.strs; ids.clear(); for (uint32_t i = 0; i < strs.size(); ++i) ids.emplace(strs[i], i); }
+    return *this;
+  }
   uint32_t id(std::string_view s) {
-    auto it = ids.find(std::string(s));
+    auto it = ids.find(s);
     if (it != ids.end()) return it->second;
     uint32_t i = (uint32_t)strs.size();
     strs.emplace_back(s);
@@ -46,7 +54,7 @@ struct StrMap {
     return i;
   }
   int find(std::string_view s) const {
-    auto it = ids.find(std::string(s));
+    auto it = ids.find(s);
     return it == ids.end() ? -1 : (int)it->second;
   }
   size_t size() const { return strs.size(); }

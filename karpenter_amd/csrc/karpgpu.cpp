@@ -103,6 +103,9 @@ void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out, bool add_po
   const kg_pools& p = d->pools;
   std::unordered_map<std::string, uint32_t> by_sig;
   out->pods.reserve(d->n_pods);
+  out->rq.reserve((size_t)d->n_pods * 4);
+  std::vector<int32_t> rid_of_str(p.strings.count, -1);
+  std::vector<std::pair<uint32_t, int64_t>> rl;
   Sig sg;
   for (uint32_t i = 0; i < d->n_pods; ++i) {
     const kg_pod& q = d->pods[i];
@@ -163,12 +166,22 @@ void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out, bool add_po
     }
     PodRef pr;
     pr.cls = cls;
-    auto rl = parse_rl(ctx->V, p, q.requests);
+    // the pod's requests, merged by resource and sorted by resource id (resource names resolved once per descriptor string)
+    rl.clear();
+    for (auto& qq : kgdesc::quantities(p, q.requests)) {
+      check(qq.name < p.strings.count, "quantity name");
+      int32_t& rid = rid_of_str[qq.name];
+      if (rid < 0) rid = (int32_t)ctx->V.resources.id(kgdesc::str(p.strings, qq.name));
+      bool found = false;
+      for (auto& kv : rl) if (kv.first == (uint32_t)rid) { kv.second += qq.milli; found = true; }
+      if (!found) rl.push_back({(uint32_t)rid, qq.milli});
+    }
     if (add_pods_one) {  // resources.RequestsForPods adds pods: 1
       bool found = false;
       for (auto& kv : rl) if (kv.first == ctx->rPods) { kv.second += 1000; found = true; }
-      if (!found) { rl.push_back({ctx->rPods, 1000}); std::sort(rl.begin(), rl.end()); }
+      if (!found) rl.push_back({ctx->rPods, 1000});
     }
+    std::sort(rl.begin(), rl.end());
     if (q.volumes.count) {  // volumes per CSI driver -> requests of the driver's internal resource
       for (auto& l : kgdesc::labels(p, q.volumes)) {
         const std::string drv(kgdesc::str(p.strings, l.key));
@@ -1845,7 +1858,12 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
   std::optional<hal::Range> phase;  // (roctx: rocprofv3 --marker-trace shows the host phases next to the launch groups)
   phase.emplace("kg_solve: host compile");
   ParsedPods pending;
-  parse_pods(ctx, pods, &pending, add_pods_one);
+  {
+    HostProf prof_;
+    KG_PROF("parse_pods");
+    parse_pods(ctx, pods, &pending, add_pods_one);
+    KG_PROF("parse_pods end");
+  }
   check(out->cap_pods >= pending.pods.size(), "pod result capacity");
   check_volumes_unshared(pending, cluster);
   SolveInputs in{ctx, catalogs[0], cluster, nodepools, &pending};
@@ -1896,6 +1914,8 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
     for (int k = 0; k < 8; ++k) fprintf(stderr, "[kg wave] %-32s %9.0f kcycles\n", sec[k], counters[64 + k] / 1e3);
     fprintf(stderr, "[kg wave] prefilter steps %llu, survivors %llu, exact evaluations %llu\n", (unsigned long long)counters[72], (unsigned long long)counters[73],
             (unsigned long long)counters[74]);
+    static const char* nsec[] = {"limits + template row", "NodeClaim.Add (fresh)", "row stores", "headroom / subtractMax", "scan order"};
+    for (int k = 0; k < 5; ++k) fprintf(stderr, "[kg wave]   new NodeClaim: %-24s %9.0f kcycles\n", nsec[k], counters[80 + k] / 1e3);
   } else if (ctx->wave_timers) {
     static const char* ph[] = {"prefilter", "wave-local Add", "commit", "fresh commit", "fresh setup", "workgroup Add", "nodes", "relax / ctx"};
     for (int k = 0; k < 8; ++k) {
@@ -1927,10 +1947,11 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
     };
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return okey(a) < okey(b); });
     hal::d2h(c_tmpl.data(), sp(C->o_ctmpl), (size_t)nclaims * 2);
-    for (int w = 0; w < TW; ++w) hal::d2h(c_mask.data() + (size_t)w * nclaims, sp(C->o_cmask) + (size_t)w * Cmax * 8, (size_t)nclaims * 8);
-    for (int w = 0; w < C->Wa; ++w) hal::d2h(c_bits.data() + (size_t)w * nclaims, sp(C->o_cbits) + (size_t)w * Cmax * 8, (size_t)nclaims * 8);
-    for (int a = 0; a < Ka; ++a) hal::d2h(c_meta.data() + (size_t)a * nclaims, sp(C->o_cmeta) + (size_t)a * Cmax * 4, (size_t)nclaims * 4);
-    for (int r = 0; r < R; ++r) hal::d2h(c_req.data() + (size_t)r * nclaims, sp(C->o_creq) + (size_t)r * Cmax * 8, (size_t)nclaims * 8);
+    // the first nclaims entries of every [row][Cmax] column: one strided copy per table (not one blocking copy per row)
+    hal::d2h_rows(c_mask.data(), sp(C->o_cmask), (size_t)nclaims * 8, (size_t)Cmax * 8, (size_t)TW);
+    hal::d2h_rows(c_bits.data(), sp(C->o_cbits), (size_t)nclaims * 8, (size_t)Cmax * 8, (size_t)C->Wa);
+    hal::d2h_rows(c_meta.data(), sp(C->o_cmeta), (size_t)nclaims * 4, (size_t)Cmax * 4, (size_t)Ka);
+    hal::d2h_rows(c_req.data(), sp(C->o_creq), (size_t)nclaims * 8, (size_t)Cmax * 8, (size_t)R);
   }
   Vocab& V = ctx->V;
   kgdesc::ResultWriter W(out);

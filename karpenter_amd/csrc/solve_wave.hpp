@@ -244,7 +244,12 @@ __device__ __forceinline__ uint64_t plain_set_or_all(uint32_t meta, uint64_t wor
 // folded signature instead of the mask (8 adjacent types per bit: instance families straddle the buckets, the false
 // survivors doubled the exact evaluations: 69 ms); whole rows in LDS with the per-pod results stored 64 at a time and the
 // next pod's context requested behind the prefilter (no global load or store left in a placement, but half as many
-// instructions again and twice the scalar-register spills: 54-55 ms).
+// instructions again and twice the scalar-register spills: 54-55 ms); three helper waves (a 256-thread workgroup, one wave per
+// SIMD) running the prefilter of the NEXT pod against every claim while this wave evaluates NodeClaim.Add, the ballots left in
+// LDS as a bit vector over scan positions that is repaired after the commit (the touched claim moves and is re-tested; two
+// LDS-only barriers per placement): bit-exact, but 53.2 ms against 50.8 -- with this wave ignoring the vectors the hand-over
+// alone cost 6.8 ms (the helpers scan every claim where the scan here stops at the first feasible one, and their LDS
+// traffic lengthens each of this wave's ~40 exposed LDS round trips), using them won back only 4.2.
 constexpr uint32_t KG_PF_HEAD = 8;  // words before the mask: h0..h3, zone, ct, template, pad
 constexpr uint32_t KG_POOL_WORDS = (160 * 1024 - (uint32_t)sizeof(SharedBase)) / 8 - 2;
 
@@ -304,6 +309,9 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
 #pragma unroll
   for (int i = 0; i < 12; ++i) wt[i] = 0;
 #define KG_W(k) do { if (WT) { const unsigned long long n_ = clock64(); if (wt_last) wt[k] += n_ - wt_last; wt_last = n_; } } while (0)
+  // ... and inside "new NodeClaim" (also counted there): limits + template row, NodeClaim.Add, row stores, headroom / limits, order
+  unsigned long long wn_last = 0, wn[5] = {0, 0, 0, 0, 0};
+#define KG_WN(k) do { if (WT) { const unsigned long long n_ = clock64(); if ((k) >= 0) wn[(k) < 0 ? 0 : (k)] += n_ - wn_last; wn_last = n_; } } while (0)
   stage_tables<64>(P, sh);
   const uint32_t Ka = (uint32_t)P.Ka, Wa = (uint32_t)P.Wa, NR = (uint32_t)P.R, TW = (uint32_t)P.TW, NP = (uint32_t)P.NP;
   const size_t Cmax = (size_t)P.Cmax;
@@ -533,6 +541,7 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
     if (__builtin_expect(!placed && nclaims < (uint32_t)P.Cmax, 0)) {
       const uint32_t c = nclaims;
       for (uint32_t t = 0; t < NP && !placed; ++t) {
+        KG_WN(-1);
         // filterByRemainingResources: types whose capacity fits what the NodePool's limits leave
         uint64_t cm = 0;
         if (lane < TW) {
@@ -562,7 +571,9 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         if (rg < NR) req = P.tmpl_req[(size_t)rg * NP + t];
         uint64_t m = cm;
         bool compat = true;
+        KG_WN(0);
         const bool feasible = wave_add<true>(P, sh, thr_rows, lt, pc, lane, need, t, meta, bits, req, m, &compat);
+        KG_WN(1);
         if (!feasible) { reason |= compat ? 8u : 2u; continue; }
         // ---- commit the new claim: appended to the end of the one-pod group
         KG_GLOBAL uint64_t* row = S.c_row + (size_t)c * KG_ROW_WORDS;
@@ -585,6 +596,7 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
             if (lane < pfw - KG_PF_HEAD) rec[KG_PF_HEAD + lane] = m;
           }
         }
+        KG_WN(2);
         for (uint32_t r = 0; r < NR; ++r) {
           const int64_t mx = wave_max_over_mask(P.alloc + (size_t)KG_UNI(sh.a_res[r]) * P.T, m, TW, (uint32_t)P.T, lane);
           const int64_t rq = (int64_t)rl64((uint64_t)req, 8 * r);
@@ -600,6 +612,7 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
           S.pod_index[pod_row(S, pod)] = (int32_t)c;
           if (P.has_ports) S.c_ports[c] = pc.vc.hp_use;
         }
+        KG_WN(3);
         const uint32_t endk = word_group_end(S, sh, lds, nclaims, 1, lane);
         // shift [endk, nclaims) right by one, from the top
         for (uint32_t hi = nclaims; hi > endk;) {
@@ -614,6 +627,7 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         last_c = c; last_new = 1;
         nclaims += 1; seq += 1;
         placed = true;
+        KG_WN(4);
       }
     }
     KG_W(6);
@@ -667,8 +681,11 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
   if (WT && lane == 0) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) S.counters[64 + i] = wt[i];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) S.counters[80 + i] = wn[i];
   }
 #undef KG_W
+#undef KG_WN
   if (lane == 0) {
     S.header[0] = nclaims;
     S.header[2] = last_c; S.header[3] = last_npods; S.header[4] = last_stamp; S.header[5] = last_new;
