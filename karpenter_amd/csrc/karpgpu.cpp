@@ -1103,7 +1103,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   const int Cmax = sim_mode ? in.sim_cmax : std::max(P, 1);
   C.Cmax = Cmax;
   const int H = N + Cmax;
-  std::vector<int32_t> hcount0((size_t)std::max(GH, 1) * H, 0), hpos0(std::max(GH, 1), 0);
+  std::vector<int32_t> hcount0(GH > 0 ? (size_t)GH * H : 2, 0), hpos0(std::max(GH, 1), 0);  // (no hostname group: nothing to count -- every simulation copies this)
   if (G > 0) {
     // universe per special key: union over templates x types of (template ∩ type) values, plus template In values
     std::vector<uint64_t> universe(std::max(nspec, 1), 0);
@@ -1395,7 +1395,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   Arena SA;
   std::vector<int64_t> remaining0(tmpl_limits0);
   std::vector<uint32_t> header(16, 0), nqueue{(uint32_t)P};
-  std::vector<uint64_t> counters(64 + 16 * 32, 0);  // [64..): per-wave cycle accounting (16 waves x 16 slots)
+  std::vector<uint64_t> counters(in.sim_cmax > 0 ? 64 : 64 + 16 * 32, 0);  // [64..): per-wave cycle accounting (16 waves x 16 slots; debug kernels of a Solve only)
   // initialised state first (it is what gets uploaded), per-claim / per-pod arrays behind it (zeroed on the device)
   // existing nodes: one Solve keeps its own [R][N] requests / [N] port words; a simulation of a batch keeps a short list of
   // the nodes it touched (behind the image) and a bit per node here
@@ -2496,6 +2496,8 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
 
   phase.reset();
   KG_PROF("cons: kernels");
+  if (prof_.on) fprintf(stderr, "[kg host] simulation state: %zu bytes per slot, %zu initialised (ntouch %zu excl %zu remaining %zu gcount %zu queue %zu header %zu counters %zu)\n",
+                        (size_t)C->state_bytes, (size_t)C->state_init_bytes, C->o_ntouch, C->o_excl, C->o_remaining, C->o_gcount, C->o_queue, C->o_header, C->o_counters);
   double ms_total = PL.ms_prepass, ms_init = 0, ms_sim = 0, ms_gather = 0;
   const float ms_pre = PL.ms_prepass;
   PL.ms_prepass = 0;  // (the prepass ran when the plan was built: charged to the first round only)

@@ -38,8 +38,8 @@ constexpr int KG_MAXSPEC = 6;   // "special" 1-word keys: zone, capacity-type, z
 constexpr int KG_MAXLIST = 8;   // topology groups consulted for one pod
 constexpr int KG_EBITS = 32;    // requirement-value words of one pod staged in LDS
 constexpr int KG_THR_LDS = 1024;  // fit-threshold values staged in LDS
-constexpr int KG_ORD = 2048;      // in-flight NodeClaims whose scan order is kept in LDS (global memory beyond)
-constexpr int KG_MAXGP = 32;      // NodeClaims evaluated exactly per pass
+constexpr int KG_ORD = 1024;      // in-flight NodeClaims whose scan order is kept in LDS (global memory beyond)
+constexpr int KG_MAXGP = 24;      // NodeClaims evaluated exactly per pass
 constexpr int KG_GP0 = 8;         // ... in the first pass over a chunk of the scan order
 constexpr int KG_ROWW = 64;       // requirement-value words of one claim row
 constexpr int KG_TWLDS = 16;      // option-mask words (<= 1024 instance types) for the tables staged in LDS
