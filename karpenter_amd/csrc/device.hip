@@ -276,6 +276,31 @@ void launch_sim_gather(const DevProblem& P, const SimBatch& B, const SimState* s
   ck(hipGetLastError(), "sim gather launch");
   *ms = t.stop();
 }
+// k_sim_init -> k_simulate -> k_sim_gather of one batch back to back: four events, ONE host synchronisation (the three
+// launch groups above each wait for their own kernel)
+void launch_sim_round(const DevProblem& P, const SimBatch& B, const SimState* sims, int block, float ms[3]) {
+  ms[0] = ms[1] = ms[2] = 0;
+  if (!B.nsims) return;
+  roctxRangePushA("kg consolidation round (k_sim_init, k_simulate, k_sim_gather)");
+  int dev = 0;
+  ck(hipGetDevice(&dev), "hipGetDevice");
+  hipEvent_t ev[4];
+  for (int i = 0; i < 4; ++i) ev[i] = Timer::take(dev);
+  ck(hipEventRecord(ev[0], t_stream), "record");
+  hipLaunchKernelGGL(k_sim_init, dim3(B.nsims), dim3(256), 0, t_stream, P, B);
+  ck(hipEventRecord(ev[1], t_stream), "record");
+  if (block >= 512) hipLaunchKernelGGL((k_simulate<512>), dim3(B.nsims), dim3(512), 0, t_stream, P, sims, B.nqueue);
+  else hipLaunchKernelGGL((k_simulate<256>), dim3(B.nsims), dim3(256), 0, t_stream, P, sims, B.nqueue);
+  ck(hipEventRecord(ev[2], t_stream), "record");
+  hipLaunchKernelGGL(k_sim_gather, dim3((B.nsims + 63) / 64), dim3(64), 0, t_stream, P, B, sims);
+  ck(hipEventRecord(ev[3], t_stream), "record");
+  ck(hipGetLastError(), "consolidation round launch");
+  ck(hipEventSynchronize(ev[3]), "kernel execution");
+  for (int i = 0; i < 3; ++i) ck(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]), "elapsed");
+  roctxRangePop();
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  for (int i = 0; i < 4; ++i) g_events[dev].push_back(ev[i]);
+}
 const char* backend() { return "hip-gfx950"; }
 
 }  // namespace hal

@@ -36,6 +36,8 @@ void launch_solve_wave(const DevProblem& P, const SimState* sims, int nsims, con
 // consolidation batches: k_sim_init (state slots from the pristine image + per-simulation patches), k_sim_gather
 void launch_sim_init(const DevProblem& P, const SimBatch& B, float* ms);
 void launch_sim_gather(const DevProblem& P, const SimBatch& B, const SimState* sims, float* ms);
+// the three of a batch back to back with one host synchronisation; ms = {init, simulate, gather}
+void launch_sim_round(const DevProblem& P, const SimBatch& B, const SimState* sims, int block, float ms[3]);
 // debug_probes.hip: the latency micro-probes (debug timers only)
 void launch_probes(const DevProblem& P, const SimState* sims, void* stream);
 // roctx ranges around the host phases of an entry point (the launch groups above carry their own)

@@ -2516,10 +2516,9 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
     B.o_gcount = C->o_gcount; B.o_gdom = C->o_gdom; B.o_gpos = C->o_gpos; B.o_hcount = C->o_hcount; B.o_hpos = C->o_hpos;
     B.pod_nonpending = (const uint8_t*)tp(PL.o_np); B.node_uninit = (const uint64_t*)tp(PL.o_un); B.nsims = (int)nb;
     const SimState* sims_dev = (const SimState*)rp_(PL.o_sims) + b0;
-    float ms_i = 0, ms_s = 0, ms_g = 0;
-    hal::launch_sim_init(C->dp, B, &ms_i);
-    hal::launch_solve(C->dp, sims_dev, (int)nb, B.nqueue, ctx->sim_block_threads, &ms_s, true);
-    hal::launch_sim_gather(C->dp, B, sims_dev, &ms_g);
+    float ms3[3] = {0, 0, 0};
+    hal::launch_sim_round(C->dp, B, sims_dev, ctx->sim_block_threads, ms3);
+    const float ms_i = ms3[0], ms_s = ms3[1], ms_g = ms3[2];
     ms_total += ms_i + ms_s + ms_g;
     ms_init += ms_i; ms_sim += ms_s; ms_gather += ms_g;
     ctx->stats.kernel_launches += 3;

@@ -160,10 +160,11 @@ class Library:
         self._check(self.dll.kg_cluster_upload(self.ctx, C.addressof(built.desc), C.byref(h)))
         return h
 
-    def solve(self, catalogs, cluster, pods, nodepools, n_pods, cap_claims=None, noalloc=False):
-        """kg_solve; noalloc=True -> kg_solve_noalloc (device tables in the library's static scratch array)."""
+    def solve(self, catalogs, cluster, pods, nodepools, n_pods, cap_claims=None, noalloc=False, out=None):
+        """kg_solve; noalloc=True -> kg_solve_noalloc (device tables in the library's static scratch array).  `out`: result
+        buffers of an earlier call to fill again (they are the caller's: a controller allocates them once)."""
         arr = (C.c_void_p * len(catalogs))(*catalogs)
-        rb = abi.ResultBuffers(n_pods, cap_claims)
+        rb = out if out is not None else abi.ResultBuffers(n_pods, cap_claims)
         fn = self.dll.kg_solve_noalloc if noalloc else self.dll.kg_solve
         self._check(fn(self.ctx, arr, len(catalogs), cluster, C.addressof(pods.desc), C.addressof(nodepools.desc),
                                       C.addressof(rb.res)))

@@ -103,13 +103,13 @@ class Problem:
         assert st == 0, "oracle status %d" % st
         return rb
 
-    def run_library(self, L, hcat=None):
+    def run_library(self, L, hcat=None, out=None):
         own = hcat is None
         if own:
             hcat = L.catalog_upload(self.cat)
         hcl = L.cluster_upload(self.cluster) if self.cluster is not None else None
         try:
-            return L.solve([hcat], hcl, self.pods, self.nodepools, self.n_pods)
+            return L.solve([hcat], hcl, self.pods, self.nodepools, self.n_pods, out=out)
         finally:
             if hcl is not None:
                 L.dll.kg_cluster_free(hcl)
