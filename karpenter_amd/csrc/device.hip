@@ -172,6 +172,12 @@ void* dmalloc(size_t bytes) {
   return p;
 }
 void dfree(void* p) { if (p) (void)hipFree(p); }
+void* host_pinned(size_t bytes) {
+  void* p = nullptr;
+  ck(hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault), "hipHostMalloc");
+  return p;
+}
+void host_pinned_free(void* p) { if (p) (void)hipHostFree(p); }
 // (copies complete before they return: the callers hand over pageable host buffers they reuse at once)
 void h2d(void* dst, const void* src, size_t bytes) {
   if (!bytes) return;

@@ -21,6 +21,8 @@ void* scratch_ptr(size_t* bytes) {
 }
 void* dmalloc(size_t bytes) { return std::calloc(bytes ? bytes : 8, 1); }
 void dfree(void* p) { std::free(p); }
+void* host_pinned(size_t bytes) { return std::malloc(bytes ? bytes : 8); }
+void host_pinned_free(void* p) { std::free(p); }
 void h2d(void* dst, const void* src, size_t bytes) { if (bytes) std::memcpy(dst, src, bytes); }
 void d2h(void* dst, const void* src, size_t bytes) { if (bytes) std::memcpy(dst, src, bytes); }
 void d2h_rows(void* dst, const void* src, size_t width, size_t spitch, size_t rows) {

@@ -20,6 +20,8 @@ void stream_destroy(void* stream);
 // the current device's copy of the static scratch array and its size (device.hip: `scratch`)
 void* scratch_ptr(size_t* bytes);
 void* dmalloc(size_t bytes);
+void* host_pinned(size_t bytes);  // page-locked host memory: a D2H into it is one DMA, no staging copy
+void host_pinned_free(void* p);
 void dfree(void* p);
 void h2d(void* dst, const void* src, size_t bytes);
 void d2h(void* dst, const void* src, size_t bytes);

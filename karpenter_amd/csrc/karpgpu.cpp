@@ -2194,7 +2194,8 @@ struct kg_cons_plan {
   DeviceBuffer arena, run;
   size_t max_batch = 0, o_sims = 0, o_unit = 0, o_nq = 0, o_res = 0;
   uint64_t last_use = 0;
-  ~kg_cons_plan() { hal::dfree(tables.ptr); hal::dfree(arena.ptr); hal::dfree(run.ptr); }
+  SimResult* results_host = nullptr;  // pinned: the simulations' outcomes come back in one DMA
+  ~kg_cons_plan() { hal::dfree(tables.ptr); hal::dfree(arena.ptr); hal::dfree(run.ptr); hal::host_pinned_free(results_host); }
 };
 void kg_cluster_drop_plans(kg_cluster* cl) { for (auto* p : cl->plans) delete p; cl->plans.clear(); }
 
@@ -2468,8 +2469,8 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
     PL.shard = cands->shard; PL.n_shards = shards;
     PL.live.clear();
     for (uint32_t k : mine) if (!units[k].skip) PL.live.push_back(k);
-    hal::dfree(PL.arena.ptr); hal::dfree(PL.run.ptr);
-    PL.arena = DeviceBuffer(); PL.run = DeviceBuffer();
+    hal::dfree(PL.arena.ptr); hal::dfree(PL.run.ptr); hal::host_pinned_free(PL.results_host);
+    PL.arena = DeviceBuffer(); PL.run = DeviceBuffer(); PL.results_host = nullptr;
     if (!PL.live.empty()) {
       const size_t stride = C->state_bytes, budget = (size_t)8 << 30, nl = PL.live.size();
       PL.max_batch = std::max<size_t>(1, std::min<size_t>(nl, budget / stride > 1 ? budget / stride - 1 : 1));
@@ -2489,6 +2490,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
       PL.run.bytes = RA.bytes.size();
       PL.run.ptr = hal::dmalloc(PL.run.bytes);
       hal::h2d(PL.run.ptr, RA.bytes.data(), PL.run.bytes);
+      PL.results_host = (SimResult*)hal::host_pinned(nl * sizeof(SimResult));
     }
   }
   const std::vector<uint32_t>& live = PL.live;
@@ -2502,7 +2504,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   const float ms_pre = PL.ms_prepass;
   PL.ms_prepass = 0;  // (the prepass ran when the plan was built: charged to the first round only)
   const size_t stride = C->state_bytes;
-  std::vector<SimResult> results(live.size());
+  SimResult* const results = PL.results_host;
   auto tp = [&](size_t off) { return (uint8_t*)PL.tables.ptr + off; };
   auto rp_ = [&](size_t off) { return (uint8_t*)PL.run.ptr + off; };
   for (size_t b0 = 0; b0 < live.size(); b0 += PL.max_batch) {
@@ -2524,12 +2526,12 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
     ctx->stats.kernel_launches += 3;
     ctx->stats.solves += nb;
   }
-  hal::d2h(results.data(), rp_(PL.o_res), live.size() * sizeof(SimResult));
+  hal::d2h(results, rp_(PL.o_res), live.size() * sizeof(SimResult));
   if (device_ms) *device_ms = ms_total;
   ctx->stats.device_ms_total += ms_total;
   {
     uint64_t v[4] = {0, 0, 0, 0};
-    for (auto& sr : results) for (int k = 0; k < 4; ++k) v[k] += sr.visited[k];
+    for (size_t i = 0; i < live.size(); ++i) for (int k = 0; k < 4; ++k) v[k] += results[i].visited[k];
     ctx->stats.cons_simulations = live.size();
     ctx->stats.cons_algorithmic_bytes = 212.0 * v[0] + 400.0 * (v[1] + v[3]) + 336.0 * v[2];
     ctx->stats.cons_prepass_ms = ms_pre; ctx->stats.cons_sim_init_ms = ms_init; ctx->stats.cons_simulate_ms = ms_sim; ctx->stats.cons_gather_ms = ms_gather;
