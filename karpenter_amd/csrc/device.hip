@@ -86,10 +86,16 @@ __global__ void __launch_bounds__(256) k_sim_init(DevProblem P, SimBatch B) {
   __syncthreads();
   sim_init_patch(P, B, blockIdx.x, threadIdx.x, blockDim.x);
 }
-// k_sim_gather: one thread per simulation condenses the outcome into a SimResult
+// k_sim_gather: one wave per simulation condenses the outcome into a SimResult (the lanes share the walk over the
+// simulation's pods: a multi-node prefix has more than a thousand)
 __global__ void __launch_bounds__(64) k_sim_gather(DevProblem P, SimBatch B, const SimState* sims) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < (uint32_t)B.nsims) sim_gather(P, B, sims[i], i);
+  const uint32_t i = blockIdx.x, lane = threadIdx.x;
+  const SimState S = sims[i];
+  uint32_t errors = 0, claim0_np = 0;
+  sim_gather_scan(B, S, i, lane, 64, &errors, &claim0_np);
+  for (int o = 32; o; o >>= 1) errors += __shfl_xor(errors, o);
+  claim0_np = __ballot(claim0_np != 0) != 0;
+  if (lane == 0) sim_gather_finish(P, B, S, i, errors, claim0_np);
 }
 
 }  // namespace kg
@@ -278,7 +284,7 @@ void launch_sim_init(const DevProblem& P, const SimBatch& B, float* ms) {
 }
 void launch_sim_gather(const DevProblem& P, const SimBatch& B, const SimState* sims, float* ms) {
   Timer t("kg k_sim_gather");
-  if (B.nsims) hipLaunchKernelGGL(k_sim_gather, dim3((B.nsims + 63) / 64), dim3(64), 0, t_stream, P, B, sims);
+  if (B.nsims) hipLaunchKernelGGL(k_sim_gather, dim3(B.nsims), dim3(64), 0, t_stream, P, B, sims);
   ck(hipGetLastError(), "sim gather launch");
   *ms = t.stop();
 }
@@ -298,7 +304,7 @@ void launch_sim_round(const DevProblem& P, const SimBatch& B, const SimState* si
   if (block >= 512) hipLaunchKernelGGL((k_simulate<512>), dim3(B.nsims), dim3(512), 0, t_stream, P, sims, B.nqueue);
   else hipLaunchKernelGGL((k_simulate<256>), dim3(B.nsims), dim3(256), 0, t_stream, P, sims, B.nqueue);
   ck(hipEventRecord(ev[2], t_stream), "record");
-  hipLaunchKernelGGL(k_sim_gather, dim3((B.nsims + 63) / 64), dim3(64), 0, t_stream, P, B, sims);
+  hipLaunchKernelGGL(k_sim_gather, dim3(B.nsims), dim3(64), 0, t_stream, P, B, sims);
   ck(hipEventRecord(ev[3], t_stream), "record");
   ck(hipGetLastError(), "consolidation round launch");
   ck(hipEventSynchronize(ev[3]), "kernel execution");

@@ -359,7 +359,8 @@ struct Compiled {
   std::vector<std::vector<uint32_t>> contrib;
   std::vector<uint64_t> gdom_univ;   // [G] domains registered from the NodePools / instance types alone
   size_t o_nports, o_cports, o_crow = 0;  // o_crow: behind the state image (device-only, never uploaded)
-  size_t o_ntouch = 0, o_tnode = 0, o_tadd = 0, o_tports = 0;
+  size_t o_ntouch = 0, o_tnode = 0, o_tadd = 0, o_tports = 0, o_thash = 0;
+  uint32_t thash_mask = 0;
   size_t o_nreq, o_creq, o_chead, o_chstamp, o_cmask, o_cbits, o_cmeta, o_cnpods, o_ctmpl, o_order, o_remaining, o_gcount, o_gdom, o_gpos, o_hcount, o_hpos, o_queue,
       o_podkind, o_excl, o_podindex, o_podreason, o_scratch, o_ordg, o_header, o_counters, o_nqueue;
   bool fixed = false;  // the device buffers are carved from a FixedArena (kg_solve_noalloc): nothing to give back
@@ -1401,7 +1402,15 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   // the nodes it touched (behind the image) and a bit per node here
   std::vector<uint64_t> ntouch0(NW, 0), excl0(NW, 0);
   if (!sim_mode) { C.o_nreq = SA.add(nreq0); C.o_nports = SA.add(nports0); C.o_ntouch = 0; }
-  else { C.o_nreq = C.o_nports = 0; C.o_ntouch = SA.add(ntouch0); }
+  else {
+    C.o_nreq = C.o_nports = 0; C.o_ntouch = SA.add(ntouch0);
+    // node -> entry of the touched list: a simulation touches at most Cmax nodes (one per placed pod); load factor <= 1/2
+    uint32_t H = 16;
+    while (H < 2u * (uint32_t)Cmax) H *= 2;
+    std::vector<uint64_t> thash0(H, 0);
+    C.o_thash = SA.add(thash0);
+    C.thash_mask = H - 1;
+  }
   C.o_excl = SA.add(excl0);
   C.o_remaining = SA.add(remaining0);
   C.o_gcount = SA.add(gcount0); C.o_gdom = SA.add(gdom0); C.o_gpos = SA.add(gpos0); C.o_hcount = SA.add(hcount0); C.o_hpos = SA.add(hpos0);
@@ -1468,6 +1477,7 @@ static SimState sim_at(const Compiled& C, uint8_t* base) {
   St.header = (uint32_t*)sptr(C.o_header); St.counters = (uint64_t*)sptr(C.o_counters);
   St.excl = (const uint64_t*)sptr(C.o_excl); St.ordg = (unsigned long long*)sptr(C.o_ordg);
   St.ntouch = (uint64_t*)sptr(C.o_ntouch); St.tnode = (uint32_t*)sptr(C.o_tnode); St.tadd = (int64_t*)sptr(C.o_tadd); St.tports = (uint64_t*)sptr(C.o_tports);
+  St.thash = (uint64_t*)sptr(C.o_thash); St.thash_mask = C.thash_mask;
   St.n_shared = (uint32_t)C.P; St.pod_base = 0; St.qcap = C.qcap;
   return St;
 }

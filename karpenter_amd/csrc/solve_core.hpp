@@ -199,6 +199,9 @@ struct SimState {
   // sparse mode (DevProblem::sparse_nodes): nodes this simulation has put pods on -- header[6] entries
   KG_GLOBAL uint64_t* ntouch;   // [NW] bit per node: it has an entry below
   KG_GLOBAL uint32_t* tnode;    // [Cmax] node (scan position)
+  KG_GLOBAL uint64_t* thash;    // [thash_mask + 1] open addressing, (node + 1) << 32 | entry, 0 = empty: node -> its entry in O(1)
+                                // (a multi-node prefix touches hundreds of nodes; every thread that meets one looks it up)
+  uint32_t thash_mask;
   KG_GLOBAL int64_t* tadd;      // [R][Cmax] requests this simulation added to it
   KG_GLOBAL uint64_t* tports;   // [Cmax] its host-port word now
   KG_GLOBAL uint64_t* c_ports;  // [Cmax] ... on the NodeClaim
@@ -773,8 +776,11 @@ KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, c
   int tk = -1;  // sparse mode: the node's entry in the simulation's touched list
   if (P.sparse_nodes) {
     if ((S.ntouch[wi] >> bi) & 1) {
-      const uint32_t nt = S.header[6];
-      for (uint32_t k = 0; k < nt; ++k) if (S.tnode[k] == n) { tk = (int)k; break; }
+      for (uint32_t h = (n * 2654435761u) & S.thash_mask;; h = (h + 1) & S.thash_mask) {
+        const uint64_t e = S.thash[h];
+        if ((uint32_t)(e >> 32) == n + 1) { tk = (int)(uint32_t)e; break; }
+        if (e == 0) break;  // (cannot happen while the bit is set)
+      }
     }
     if (P.has_ports && ((tk >= 0 ? S.tports[tk] : P.nports0[n]) & pc.vc.hp_conf)) { *reason |= 2; return false; }  // HostPortUsage.Conflicts
     // resources first (cheap reject), as upstream does
@@ -811,6 +817,11 @@ KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, c
         tk = (int)S.header[6];
         S.header[6] = (uint32_t)tk + 1;
         S.tnode[tk] = n;
+        {
+          uint32_t h = (n * 2654435761u) & S.thash_mask;
+          while (S.thash[h] != 0) h = (h + 1) & S.thash_mask;
+          S.thash[h] = ((uint64_t)(n + 1) << 32) | (uint32_t)tk;
+        }
         for (int r = 0; r < P.R; ++r) S.tadd[(size_t)r * P.Cmax + tk] = 0;
         S.tports[tk] = P.has_ports ? P.nports0[n] : 0;
         S.ntouch[wi] |= 1ull << bi;
@@ -1853,24 +1864,27 @@ KG_HD void sim_init_patch(const DevProblem& P, const SimBatch& B, uint32_t i, ui
 }
 
 // compact result of simulation i (one thread)
-KG_HD void sim_gather(const DevProblem& P, const SimBatch& B, const SimState& S, uint32_t i) {
-  SimResult r;
-  r.nclaims = S.header[0];
-  r.errors = 0;
-  uint32_t claim0_np = 0;
+// the pods of simulation i, every `step`-th from `first` on (one thread: 0, 1; one wave: lane, 64): non-pending pods that
+// did not schedule (or landed on a node that is not initialised), and whether one of them sits on NodeClaim 0
+KG_HD void sim_gather_scan(const SimBatch& B, const SimState& S, uint32_t i, uint32_t first, uint32_t step, uint32_t* errors, uint32_t* claim0_np) {
   const uint32_t u = B.unit_of_sim[i];
-  for (uint32_t k = B.q_off[u]; k < B.q_off[u + 1]; ++k) {
+  for (uint32_t k = B.q_off[u] + first; k < B.q_off[u + 1]; k += step) {
     const uint32_t pod = B.q_ent[k].x;
     if (!B.pod_nonpending[pod]) continue;
     const uint32_t row = pod_row(S, pod);
     const uint8_t kind = S.pod_kind[row];
-    if (kind == 2 && S.pod_index[row] == 0) claim0_np = 1;
-    if (kind == 0) r.errors++;
+    if (kind == 2 && S.pod_index[row] == 0) *claim0_np = 1;
+    if (kind == 0) *errors += 1;
     else if (kind == 1) {
       const uint32_t n = (uint32_t)S.pod_index[row];
-      if ((B.node_uninit[n >> 6] >> (n & 63)) & 1) r.errors++;
+      if ((B.node_uninit[n >> 6] >> (n & 63)) & 1) *errors += 1;
     }
   }
+}
+KG_HD void sim_gather_finish(const DevProblem& P, const SimBatch& B, const SimState& S, uint32_t i, uint32_t errors, uint32_t claim0_np) {
+  SimResult r;
+  r.nclaims = S.header[0];
+  r.errors = errors;
   r.tmpl = 0; r.n_pods = 0; r.zone_meta = r.ct_meta = r.zid_meta = 0; r.pad = claim0_np; r.zone_word = r.ct_word = r.zid_word = 0;
   for (int w = 0; w < KG_TWLDS; ++w) r.mask[w] = 0;
   if (r.nclaims == 1) {
@@ -1883,6 +1897,11 @@ KG_HD void sim_gather(const DevProblem& P, const SimBatch& B, const SimState& S,
   }
   for (int k = 0; k < 4; ++k) r.visited[k] = S.counters[k];
   B.results[i] = r;
+}
+KG_HD void sim_gather(const DevProblem& P, const SimBatch& B, const SimState& S, uint32_t i) {
+  uint32_t errors = 0, claim0_np = 0;
+  sim_gather_scan(B, S, i, 0, 1, &errors, &claim0_np);
+  sim_gather_finish(P, B, S, i, errors, claim0_np);
 }
 
 }  // namespace kg
