@@ -771,32 +771,46 @@ template <bool COMMIT>
 KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, const PodCtx& pc, uint32_t n, uint32_t* reason) {
   const Variant& v = pc.vc.v;
   const uint32_t wi = n >> 6, bi = n & 63;
-  if ((S.excl[wi] >> bi) & 1) return false;  // a candidate of this simulation: not a state node
-  if (!((P.ntol[(size_t)v.tolset * P.NW + wi] >> bi) & 1)) { *reason |= 1; return false; }
+  // Every word the checks below may look at is requested before the first one is used: one round trip for the node instead
+  // of one per check (each `return` below would otherwise put a wait and a branch in front of the next load).
+  const uint64_t w_excl = S.excl[wi], w_tol = P.ntol[(size_t)v.tolset * P.NW + wi], w_lab = P.nlab[(size_t)v.rs * P.NW + wi];
+  const uint64_t w_touch = P.sparse_nodes ? S.ntouch[wi] : 0ull;
+  const uint64_t w_ports = !P.has_ports ? 0ull : (P.sparse_nodes ? P.nports0[n] : S.nports[n]);
+  int64_t n_av[KG_MAXR], n_rq[KG_MAXR];
+#pragma unroll
+  for (int r = 0; r < KG_MAXR; ++r) {
+    const size_t at = (size_t)(r < P.R ? r : 0) * P.N + n;
+    n_av[r] = P.navail[at];
+    n_rq[r] = P.sparse_nodes ? P.nreq0[at] : S.nreq[at];
+  }
+  if ((w_excl >> bi) & 1) return false;  // a candidate of this simulation: not a state node
+  if (!((w_tol >> bi) & 1)) { *reason |= 1; return false; }
   int tk = -1;  // sparse mode: the node's entry in the simulation's touched list
   if (P.sparse_nodes) {
-    if ((S.ntouch[wi] >> bi) & 1) {
+    if ((w_touch >> bi) & 1) {
       for (uint32_t h = (n * 2654435761u) & S.thash_mask;; h = (h + 1) & S.thash_mask) {
         const uint64_t e = S.thash[h];
         if ((uint32_t)(e >> 32) == n + 1) { tk = (int)(uint32_t)e; break; }
         if (e == 0) break;  // (cannot happen while the bit is set)
       }
     }
-    if (P.has_ports && ((tk >= 0 ? S.tports[tk] : P.nports0[n]) & pc.vc.hp_conf)) { *reason |= 2; return false; }  // HostPortUsage.Conflicts
+    if (P.has_ports && ((tk >= 0 ? S.tports[tk] : w_ports) & pc.vc.hp_conf)) { *reason |= 2; return false; }  // HostPortUsage.Conflicts
     // resources first (cheap reject), as upstream does
-    for (int r = 0; r < P.R; ++r) {
-      if (pc.preq[r] == 0) continue;
-      const int64_t have = P.nreq0[(size_t)r * P.N + n] + (tk >= 0 ? S.tadd[(size_t)r * P.Cmax + tk] : 0);
-      if (have + pc.preq[r] > P.navail[(size_t)r * P.N + n]) { *reason |= 64; return false; }
+#pragma unroll
+    for (int r = 0; r < KG_MAXR; ++r) {
+      if (r >= P.R || pc.preq[r] == 0) continue;
+      const int64_t have = n_rq[r] + (tk >= 0 ? S.tadd[(size_t)r * P.Cmax + tk] : 0);
+      if (have + pc.preq[r] > n_av[r]) { *reason |= 64; return false; }
     }
   } else {
-    if (P.has_ports && (S.nports[n] & pc.vc.hp_conf)) { *reason |= 2; return false; }  // HostPortUsage.Conflicts
+    if (P.has_ports && (w_ports & pc.vc.hp_conf)) { *reason |= 2; return false; }  // HostPortUsage.Conflicts
     // resources first (cheap reject), as upstream does
-    for (int r = 0; r < P.R; ++r) {
-      if (pc.preq[r] != 0 && S.nreq[(size_t)r * P.N + n] + pc.preq[r] > P.navail[(size_t)r * P.N + n]) { *reason |= 64; return false; }
+#pragma unroll
+    for (int r = 0; r < KG_MAXR; ++r) {
+      if (r < P.R && pc.preq[r] != 0 && n_rq[r] + pc.preq[r] > n_av[r]) { *reason |= 64; return false; }
     }
   }
-  if (!((P.nlab[(size_t)v.rs * P.NW + wi] >> bi) & 1)) { *reason |= 2; return false; }
+  if (!((w_lab >> bi) & 1)) { *reason |= 2; return false; }
   for (uint32_t li = 0; li < pc.vc.nlist; ++li) {
     const ListEntry le = pc.vc.lst[li].le;
     const Group g = pc.vc.lst[li].g;
