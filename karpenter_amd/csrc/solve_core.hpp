@@ -40,6 +40,7 @@ constexpr int KG_EBITS = 32;    // requirement-value words of one pod staged in 
 constexpr int KG_THR_LDS = 1024;  // fit-threshold values staged in LDS
 constexpr int KG_ORD = 1024;      // in-flight NodeClaims whose scan order is kept in LDS (global memory beyond)
 constexpr int KG_MAXGP = 24;      // NodeClaims evaluated exactly per pass
+constexpr int KG_NTMAX = 1024;    // threads of the largest workgroup solve_block is instantiated for
 constexpr int KG_GP0 = 8;         // ... in the first pass over a chunk of the scan order
 constexpr int KG_ROWW = 64;       // requirement-value words of one claim row
 constexpr int KG_TWLDS = 16;      // option-mask words (<= 1024 instance types) for the tables staged in LDS
@@ -289,7 +290,9 @@ struct SharedBase {
 // the LDS on its prefilter records instead)
 struct Shared : SharedBase {
   Row rows[KG_MAXGP];                    // evaluation groups of the current pass
+  int32_t ntk[KG_NTMAX];                 // existing-node scan: touched entry of the node each thread found feasible (commit_node)
 };
+static_assert(sizeof(Shared) <= 80 * 1024, "two workgroups of k_simulate share a CU's 160 KB of LDS");
 
 
 // ------------------------------------------------------------------ requirement algebra
@@ -767,14 +770,16 @@ KG_HD void claim_refresh_head(const DevProblem& P, const SimState& S, const Shar
 }
 
 // ------------------------------------------------------------------ ExistingNode.Add for node n (scan position)
-template <bool COMMIT>
-KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, const PodCtx& pc, uint32_t n, uint32_t* reason) {
+// *tk_out: (sparse mode) the node's entry in the simulation's touched list as this evaluation found it, -1 when it has none
+KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, const PodCtx& pc, uint32_t n, uint32_t* reason, int* tk_out) {
   const Variant& v = pc.vc.v;
   const uint32_t wi = n >> 6, bi = n & 63;
   // Every word the checks below may look at is requested before the first one is used: one round trip for the node instead
   // of one per check (each `return` below would otherwise put a wait and a branch in front of the next load).
   const uint64_t w_excl = S.excl[wi], w_tol = P.ntol[(size_t)v.tolset * P.NW + wi], w_lab = P.nlab[(size_t)v.rs * P.NW + wi];
   const uint64_t w_touch = P.sparse_nodes ? S.ntouch[wi] : 0ull;
+  const uint32_t h0 = (n * 2654435761u) & S.thash_mask;
+  const uint64_t e0 = P.sparse_nodes ? S.thash[h0] : 0ull;  // the node's home slot: nearly always where its entry is
   const uint64_t w_ports = !P.has_ports ? 0ull : (P.sparse_nodes ? P.nports0[n] : S.nports[n]);
   int64_t n_av[KG_MAXR], n_rq[KG_MAXR];
 #pragma unroll
@@ -788,10 +793,12 @@ KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, c
   int tk = -1;  // sparse mode: the node's entry in the simulation's touched list
   if (P.sparse_nodes) {
     if ((w_touch >> bi) & 1) {
-      for (uint32_t h = (n * 2654435761u) & S.thash_mask;; h = (h + 1) & S.thash_mask) {
-        const uint64_t e = S.thash[h];
+      uint64_t e = e0;
+      for (uint32_t h = h0;;) {
         if ((uint32_t)(e >> 32) == n + 1) { tk = (int)(uint32_t)e; break; }
         if (e == 0) break;  // (cannot happen while the bit is set)
+        h = (h + 1) & S.thash_mask;
+        e = S.thash[h];
       }
     }
     if (P.has_ports && ((tk >= 0 ? S.tports[tk] : w_ports) & pc.vc.hp_conf)) { *reason |= 2; return false; }  // HostPortUsage.Conflicts
@@ -825,42 +832,55 @@ KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, c
     TopoOut o = topo_small(P, S, g, le.g, self, podDom, 1ull << d);
     if (!o.ok || !((o.opts >> d) & 1)) { *reason |= 4; return false; }
   }
-  if (COMMIT) {
-    if (P.sparse_nodes) {
-      if (tk < 0) {  // (one thread commits: the list grows by at most one entry per placed pod, Cmax in all)
-        tk = (int)S.header[6];
-        S.header[6] = (uint32_t)tk + 1;
-        S.tnode[tk] = n;
-        {
-          uint32_t h = (n * 2654435761u) & S.thash_mask;
-          while (S.thash[h] != 0) h = (h + 1) & S.thash_mask;
-          S.thash[h] = ((uint64_t)(n + 1) << 32) | (uint32_t)tk;
-        }
-        for (int r = 0; r < P.R; ++r) S.tadd[(size_t)r * P.Cmax + tk] = 0;
-        S.tports[tk] = P.has_ports ? P.nports0[n] : 0;
-        S.ntouch[wi] |= 1ull << bi;
-      }
-      for (int r = 0; r < P.R; ++r) if (pc.preq[r] != 0) S.tadd[(size_t)r * P.Cmax + tk] += pc.preq[r];
-      if (P.has_ports) S.tports[tk] |= pc.vc.hp_use;
-    } else {
-      for (int r = 0; r < P.R; ++r) if (pc.preq[r] != 0) S.nreq[(size_t)r * P.N + n] += pc.preq[r];
-      if (P.has_ports) S.nports[n] |= pc.vc.hp_use;
-    }
-    for (uint32_t li = 0; li < v.record_cnt; ++li) {
-      const ListEntry le = P.lists[v.record_off + li];
-      const Group g = P.groups[le.g];
-      if (!(le.flags & LF_INVERSE) && g.filter_cnt) {
-        bool match = false;
-        for (uint32_t f = 0; f < g.filter_cnt && !match; ++f)
-          match = (P.nlab[(size_t)P.filters[g.filter_off + f] * P.NW + wi] >> bi) & 1;
-        if (!match) continue;
-      }
-      if (g.spec == 0xFF) { record_host(S, P, g, n); continue; }
-      const uint16_t d = P.ndom[(size_t)g.spec * P.N + n];
-      if (d != 0xFFFF) record_small(S, le.g, d);
-    }
-  }
+  *tk_out = tk;
   return true;
+}
+
+// ExistingNode.Add's state update for the node the scan chose (one thread).  Nothing is evaluated again: the state has not
+// changed since the scan.  tk: the node's touched entry as its evaluation found it (-1: none yet, it becomes entry
+// `ntouched`, the simulation's count so far -- the caller keeps that count; header[6] is only written for k_sim_gather).
+KG_HD void commit_node(const DevProblem& P, const SimState& S, const PodCtx& pc, uint32_t n, int tk, uint32_t ntouched) {
+  const Variant& v = pc.vc.v;
+  const uint32_t wi = n >> 6, bi = n & 63;
+  if (P.sparse_nodes) {
+    if (tk < 0) {  // (the list grows by at most one entry per placed pod, Cmax in all)
+      tk = (int)ntouched;
+      uint32_t h = (n * 2654435761u) & S.thash_mask;
+      uint64_t e = S.thash[h];
+      const uint64_t w_touch = S.ntouch[wi];
+      const uint64_t w_ports = P.has_ports ? P.nports0[n] : 0ull;
+      while (e != 0) { h = (h + 1) & S.thash_mask; e = S.thash[h]; }
+      S.thash[h] = ((uint64_t)(n + 1) << 32) | (uint32_t)tk;
+      S.header[6] = (uint32_t)tk + 1;
+      S.tnode[tk] = n;
+      S.ntouch[wi] = w_touch | (1ull << bi);
+      for (int r = 0; r < P.R; ++r) S.tadd[(size_t)r * P.Cmax + tk] = pc.preq[r];
+      S.tports[tk] = w_ports | (P.has_ports ? pc.vc.hp_use : 0ull);
+    } else {
+      int64_t have[KG_MAXR];
+#pragma unroll
+      for (int r = 0; r < KG_MAXR; ++r) have[r] = S.tadd[(size_t)(r < P.R ? r : 0) * P.Cmax + tk];
+#pragma unroll
+      for (int r = 0; r < KG_MAXR; ++r) if (r < P.R && pc.preq[r] != 0) S.tadd[(size_t)r * P.Cmax + tk] = have[r] + pc.preq[r];
+      if (P.has_ports) S.tports[tk] |= pc.vc.hp_use;
+    }
+  } else {
+    for (int r = 0; r < P.R; ++r) if (pc.preq[r] != 0) S.nreq[(size_t)r * P.N + n] += pc.preq[r];
+    if (P.has_ports) S.nports[n] |= pc.vc.hp_use;
+  }
+  for (uint32_t li = 0; li < v.record_cnt; ++li) {
+    const ListEntry le = P.lists[v.record_off + li];
+    const Group g = P.groups[le.g];
+    if (!(le.flags & LF_INVERSE) && g.filter_cnt) {
+      bool match = false;
+      for (uint32_t f = 0; f < g.filter_cnt && !match; ++f)
+        match = (P.nlab[(size_t)P.filters[g.filter_off + f] * P.NW + wi] >> bi) & 1;
+      if (!match) continue;
+    }
+    if (g.spec == 0xFF) { record_host(S, P, g, n); continue; }
+    const uint16_t d = P.ndom[(size_t)g.spec * P.N + n];
+    if (d != 0xFFFF) record_small(S, le.g, d);
+  }
 }
 
 // row of a pod in the per-simulation result arrays
@@ -1251,12 +1271,13 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
 #define KG_SYNCW(ph) do { KG_W(2 * (ph)); KG_SYNC(); KG_W(2 * (ph) + 1); } while (0)
   const uint32_t TWP = (uint32_t)P.TWP;      // threads per evaluation group (power of two >= max(TW, 16))
   const uint32_t GP = (NT / TWP) < (uint32_t)KG_MAXGP ? (NT / TWP) : (uint32_t)KG_MAXGP;  // claims evaluated per pass
-  static_assert(NT % 64 == 0 && NT / 64 <= 16, "one ballot word per wave");
+  static_assert(NT % 64 == 0 && NT / 64 <= 16 && NT <= KG_NTMAX, "one ballot word per wave");
   stage_tables<NT>(P, sh);
   const uint32_t QCAP = S.qcap;
   // ---- uniform state of the Solve
   uint32_t qhead = 0, qlen = n_queue, epoch = 1;   // Queue ring; epoch/len implement lastLen
   uint32_t nclaims = 0, seq = 0;                   // in-flight NodeClaims, placement steps
+  uint32_t ntouched = 0;                           // sparse mode: entries of the simulation's touched-node list
   uint32_t ob = 0;                                 // current buffer of the scan order
   bool ord_lds = true;                             // scan order still in LDS
   uint32_t last_c = KG_NOIDX, last_npods = 0, last_stamp = 0, last_new = 0;  // the one claim touched since the reference's last sort
@@ -1301,7 +1322,8 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
         const uint32_t n = base + tid;
         if (n < (uint32_t)P.N) {
           uint32_t reason = 0;
-          if (eval_node<false>(P, S, sh, pc, n, &reason)) atomic_min_u32(&sh.best2[bslot], n);
+          int tk = -1;
+          if (eval_node(P, S, sh, pc, n, &reason, &tk)) { sh.ntk[tid] = tk; atomic_min_u32(&sh.best2[bslot], n); }
         }
         if (tid == 0) sh.best2[bslot ^ 1] = KG_NOIDX;  // (last read one placement ago)
         if (want_pf) ctx_fetch<NT>(P, nx, tid, qe_next.x, qe_next.y);
@@ -1311,16 +1333,18 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
       if (KG_UNI(sh.best2[bslot]) != KG_NOIDX) break;
     }
     if (P.N > 0 && KG_UNI(sh.best2[bslot]) != KG_NOIDX) {
+      const uint32_t bn_u = KG_UNI(sh.best2[bslot]);
+      const int tk_u = (int)KG_UNI((uint32_t)sh.ntk[bn_u % NT]);  // (chunks start at multiples of NT: the thread that evaluated it)
       KG_FOR_THREADS(tid, NT) {
         if (tid == 0) {
-          uint32_t reason = 0;
-          const uint32_t bn = sh.best2[bslot];
-          eval_node<true>(P, S, sh, pc, bn, &reason);
+          const uint32_t bn = bn_u;
+          commit_node(P, S, pc, bn, tk_u, ntouched);
           S.pod_kind[pod_row(S, pod)] = 1;
           S.pod_index[pod_row(S, pod)] = (int32_t)bn;
           if (STATS) S.counters[0] += bn + 1;
         }
       }
+      if (P.sparse_nodes && tk_u < 0) ntouched += 1;
       KG_SYNCW(6);
       KG_T(1);
       continue;
