@@ -61,12 +61,13 @@ __global__ void __launch_bounds__(NT) k_solve(DevProblem Pin, const SimState* si
 
 // k_simulate: the same solve loop, one workgroup per consolidation simulation (a kernel of its own so that profiles keep
 // the one persistent Solve and the batches of simulations apart)
-template <int NT>
-__global__ void __launch_bounds__(NT) k_simulate(DevProblem Pin, const SimState* sims, const uint32_t* nqueue) {
+// (second launch bound: two waves per SIMD, i.e. two 256-thread workgroups per CU -- the register budget that goes with it)
+template <int NT, bool DBG>
+__global__ void __launch_bounds__(NT, 2) k_simulate(DevProblem Pin, const SimState* sims, const uint32_t* nqueue) {
   __shared__ Shared sh;
   const DevProblem& P = Pin;
   const SimState S = sims[blockIdx.x];
-  solve_block<NT, false>(P, S, sh, nqueue[blockIdx.x]);
+  solve_block<NT, DBG>(P, S, sh, nqueue[blockIdx.x]);
 }
 
 // k_solve_wave: one WAVE = one Scheduler.Solve (solve_wave.hpp: batches without topology groups / existing nodes / minValues)
@@ -255,8 +256,8 @@ void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms) {
 void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int block, float* ms, bool batch) {
   Timer t("kg solve (k_solve / k_simulate)");
   if (batch) {
-    if (block >= 512) hipLaunchKernelGGL((k_simulate<512>), dim3(nsims), dim3(512), 0, t_stream, P, sims, nqueue);
-    else hipLaunchKernelGGL((k_simulate<256>), dim3(nsims), dim3(256), 0, t_stream, P, sims, nqueue);
+    if (block >= 512) hipLaunchKernelGGL((k_simulate<512, false>), dim3(nsims), dim3(512), 0, t_stream, P, sims, nqueue);
+    else hipLaunchKernelGGL((k_simulate<256, false>), dim3(nsims), dim3(256), 0, t_stream, P, sims, nqueue);
     ck(hipGetLastError(), "simulate launch");
     *ms = t.stop();
     return;
@@ -301,8 +302,9 @@ void launch_sim_round(const DevProblem& P, const SimBatch& B, const SimState* si
   ck(hipEventRecord(ev[0], t_stream), "record");
   hipLaunchKernelGGL(k_sim_init, dim3(B.nsims), dim3(256), 0, t_stream, P, B);
   ck(hipEventRecord(ev[1], t_stream), "record");
-  if (block >= 512) hipLaunchKernelGGL((k_simulate<512>), dim3(B.nsims), dim3(512), 0, t_stream, P, sims, B.nqueue);
-  else hipLaunchKernelGGL((k_simulate<256>), dim3(B.nsims), dim3(256), 0, t_stream, P, sims, B.nqueue);
+  if (P.stats & 8) hipLaunchKernelGGL((k_simulate<256, true>), dim3(B.nsims), dim3(256), 0, t_stream, P, sims, B.nqueue);  // (debug: per-wave cycle accounting)
+  else if (block >= 512) hipLaunchKernelGGL((k_simulate<512, false>), dim3(B.nsims), dim3(512), 0, t_stream, P, sims, B.nqueue);
+  else hipLaunchKernelGGL((k_simulate<256, false>), dim3(B.nsims), dim3(256), 0, t_stream, P, sims, B.nqueue);
   ck(hipEventRecord(ev[2], t_stream), "record");
   hipLaunchKernelGGL(k_sim_gather, dim3(B.nsims), dim3(64), 0, t_stream, P, B, sims);
   ck(hipEventRecord(ev[3], t_stream), "record");

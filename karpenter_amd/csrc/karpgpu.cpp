@@ -1315,6 +1315,9 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
 
   KG_PROF("pack the problem image");
   // ---- pack the problem image
+  // (ExistingNode.Add's fit test requests + pod <= available, kept as pod <= available - requests: one word per resource)
+  std::vector<int64_t> nfree0(navail.size());
+  for (size_t i = 0; i < navail.size(); ++i) nfree0[i] = navail[i] - nreq0[i];
   Arena A;
   const size_t o_aoff = A.add(C.aoff), o_aw = A.add(C.aw), o_s2s = A.add(C.slot2spec), o_ss = A.add(C.spec_slot), o_kU = A.add(kU), o_kN = A.add(kN),
                o_ktoff = A.add(ktwv_off), o_ktn = A.add(ktwv_n), o_vrank = A.add(vrank), o_bnd = A.add(bnd_off), o_gtval = A.add(gtval),
@@ -1323,12 +1326,12 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
                o_vctx = A.add(vctx), o_pv0 = A.add(pod_variant0), o_preq = A.add(preq),
                o_queue0 = A.add(queue0), o_lists = A.add(lists), o_tmplrs = A.add(tmpl_rs), o_tmplreq = A.add(tmpl_req),
                o_thl = A.add(tmpl_has_limits), o_tl0 = A.add(tmpl_limits0), o_tlr = A.add(tmpl_limit_res), o_toltmpl = A.add(tol_tmpl),
-               o_minvoff = A.add(tmpl_minv_off), o_minvslot = A.add(minv_slot), o_minvmin = A.add(minv_min), o_navail = A.add(navail),
-               o_ntol = A.add(ntol), o_ndom = A.add(ndom), o_groups = A.add(dgroups), o_nreq0 = A.add(nreq0), o_nports0 = A.add(nports0),
+               o_minvoff = A.add(tmpl_minv_off), o_minvslot = A.add(minv_slot), o_minvmin = A.add(minv_min), o_nfree0 = A.add(nfree0),
+               o_ntol = A.add(ntol), o_ndom = A.add(ndom), o_groups = A.add(dgroups), o_nports0 = A.add(nports0),
                o_filters = A.add(filters), o_nval = A.add(nval), o_rhm = A.add(rs_host_meta), o_rho = A.add(rs_host_off), o_rhn = A.add(rs_host_nodes);
   // kernel outputs (and the small table uploaded below) live behind the host image: never materialised on the host
   const size_t o_amask = A.reserve_tail((size_t)std::max(E, 1u) * TW * 8), o_podmask = A.reserve_tail((size_t)std::max(NV, 1) * TW * 8),
-               o_pctx = A.reserve_tail(sim_mode ? 8 : (size_t)std::max(NV, 1) * sizeof(PodCtx)), o_atab = A.reserve_tail(5 * KG_MAXR * 4),
+               o_pctx = A.reserve_tail((size_t)std::max(NV, 1) * sizeof(PodCtx)), o_atab = A.reserve_tail(5 * KG_MAXR * 4),
                o_nlab = A.reserve_tail((size_t)std::max(S, 1) * NW * 8);
   C.prob_dev.bytes = A.total();
   C.fixed = in.fixed != nullptr;
@@ -1353,7 +1356,8 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     for (int sp = 0; sp < nspec; ++sp) ok = ok && ktwv_n[C.spec_slot[sp]] <= KG_SPV;
     C.wave_ok = ok;
   }
-  D.TWP = TWP; D.NV = NV; D.stats = (stats ? 1 : 0) | (ctx->collect_timers ? 2 : 0) | (ctx->no_fast_path ? 4 : 0) | (ctx->wave_timers ? 8 : 0);  // (DevProblem::stats bit 2 = no wave-local evaluation)
+  D.TWP = TWP; D.NV = NV; D.stats = (stats ? 1 : 0) | (ctx->collect_timers ? 2 : 0) | (ctx->no_fast_path ? 4 : 0) | (ctx->wave_timers ? 8 : 0) |
+            (ctx->collect_timers && sim_mode ? 16 : 0);  // (DevProblem::stats bit 2 = no wave-local evaluation, bit 4 = simulations leave their time stamps)
   for (int r = 0; r < R; ++r) {
     const uint32_t g = C.act_res[r];
     const uint32_t* toff = (const uint32_t*)(CT.image.bytes.data() + CT.o_thr_off);
@@ -1384,24 +1388,24 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   D.cthr_val = (const int64_t*)cptr(CT.o_cthr_val); D.cthr_mask = (const uint64_t*)cptr(CT.o_cthr_mask); D.valid_types = (const uint64_t*)cptr(CT.o_valid);
   D.cap = (const int64_t*)cptr(CT.o_cap); D.alloc = (const int64_t*)cptr(CT.o_alloc); D.offmask = (const uint64_t*)cptr(CT.o_offmask); D.zone_zid = (const uint8_t*)cptr(CT.o_zone_zid);
   D.n_zone_vals = (int)CT.n_zone_vals; D.n_ct_vals = (int)CT.n_ct_vals;
-  D.sparse_nodes = sim_mode ? 1u : 0u; D.nreq0 = (const int64_t*)dptr(o_nreq0); D.nports0 = (const uint64_t*)dptr(o_nports0);
-  D.navail = (const int64_t*)dptr(o_navail); D.nlab = (const uint64_t*)dptr(o_nlab); D.ntol = (const uint64_t*)dptr(o_ntol);
+  D.sparse_nodes = sim_mode ? 1u : 0u; D.nfree0 = (const int64_t*)dptr(o_nfree0); D.nports0 = (const uint64_t*)dptr(o_nports0);
+  D.nlab = (const uint64_t*)dptr(o_nlab); D.ntol = (const uint64_t*)dptr(o_ntol);
   D.ndom = (const uint16_t*)dptr(o_ndom); D.groups = (const Group*)dptr(o_groups); D.filters = (const uint32_t*)dptr(o_filters);
   PrepassTables& X = C.pre;
   X.E = E; X.nval = (const uint16_t*)dptr(o_nval); X.rs_host_meta = (const uint32_t*)dptr(o_rhm); X.rs_host_off = (const uint32_t*)dptr(o_rho);
-  X.rs_host_nodes = (const uint32_t*)dptr(o_rhn); X.e_amask_out = (uint64_t*)dptr(o_amask); X.nlab_out = (uint64_t*)dptr(o_nlab); X.podmask_out = (uint64_t*)dptr(o_podmask); X.pctx_out = sim_mode ? nullptr : (PodCtx*)dptr(o_pctx);
+  X.rs_host_nodes = (const uint32_t*)dptr(o_rhn); X.e_amask_out = (uint64_t*)dptr(o_amask); X.nlab_out = (uint64_t*)dptr(o_nlab); X.podmask_out = (uint64_t*)dptr(o_podmask); X.pctx_out = (PodCtx*)dptr(o_pctx);
 
   KG_PROF("simulation state image");
   // ---- simulation state image
   Arena SA;
   std::vector<int64_t> remaining0(tmpl_limits0);
   std::vector<uint32_t> header(16, 0), nqueue{(uint32_t)P};
-  std::vector<uint64_t> counters(in.sim_cmax > 0 ? 64 : 64 + 16 * 32, 0);  // [64..): per-wave cycle accounting (16 waves x 16 slots; debug kernels of a Solve only)
+  std::vector<uint64_t> counters(in.sim_cmax > 0 && !ctx->wave_timers ? 64 : 64 + 16 * 32, 0);  // [64..): per-wave cycle accounting (16 waves x 16 slots; debug kernels of a Solve only)
   // initialised state first (it is what gets uploaded), per-claim / per-pod arrays behind it (zeroed on the device)
   // existing nodes: one Solve keeps its own [R][N] requests / [N] port words; a simulation of a batch keeps a short list of
   // the nodes it touched (behind the image) and a bit per node here
   std::vector<uint64_t> ntouch0(NW, 0), excl0(NW, 0);
-  if (!sim_mode) { C.o_nreq = SA.add(nreq0); C.o_nports = SA.add(nports0); C.o_ntouch = 0; }
+  if (!sim_mode) { C.o_nreq = SA.add(nfree0); C.o_nports = SA.add(nports0); C.o_ntouch = 0; }
   else {
     C.o_nreq = C.o_nports = 0; C.o_ntouch = SA.add(ntouch0);
     // node -> entry of the touched list: a simulation touches at most Cmax nodes (one per placed pod); load factor <= 1/2
@@ -1469,7 +1473,7 @@ static SimState sim_at(const Compiled& C, uint8_t* base) {
   auto sptr = [&](size_t off) { return base + off; };
   SimState St{};
   St.nports = (uint64_t*)sptr(C.o_nports); St.c_ports = (uint64_t*)sptr(C.o_cports); St.c_row = (uint64_t*)sptr(C.o_crow);
-  St.nreq = (int64_t*)sptr(C.o_nreq); St.c_req = (int64_t*)sptr(C.o_creq); St.c_head = (int64_t*)sptr(C.o_chead); St.c_hstamp = (uint32_t*)sptr(C.o_chstamp); St.c_mask = (uint64_t*)sptr(C.o_cmask); St.c_bits = (uint64_t*)sptr(C.o_cbits);
+  St.nfree = (int64_t*)sptr(C.o_nreq); St.c_req = (int64_t*)sptr(C.o_creq); St.c_head = (int64_t*)sptr(C.o_chead); St.c_hstamp = (uint32_t*)sptr(C.o_chstamp); St.c_mask = (uint64_t*)sptr(C.o_cmask); St.c_bits = (uint64_t*)sptr(C.o_cbits);
   St.c_meta = (uint32_t*)sptr(C.o_cmeta); St.c_npods = (uint32_t*)sptr(C.o_cnpods); St.c_tmpl = (uint16_t*)sptr(C.o_ctmpl); St.c_stamp = (uint32_t*)sptr(C.o_order);
   St.remaining = (int64_t*)sptr(C.o_remaining); St.gcount = (int32_t*)sptr(C.o_gcount); St.gdom = (uint64_t*)sptr(C.o_gdom); St.gpos = (uint64_t*)sptr(C.o_gpos);
   St.hcount = (int32_t*)sptr(C.o_hcount); St.hpos = (int32_t*)sptr(C.o_hpos); St.queue = (uint32_t*)sptr(C.o_queue); St.pod_kind = (uint8_t*)sptr(C.o_podkind);
@@ -2538,6 +2542,50 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   }
   hal::d2h(results, rp_(PL.o_res), live.size() * sizeof(SimResult));
   if (device_ms) *device_ms = ms_total;
+  if (C->dp.stats & 8) {
+    // debug (kg_set_collect_stats bit 5): per-wave cycle accounting of the batch's simulations, summed
+    const size_t nb = std::min(PL.max_batch, live.size()), W = 16 * 32;
+    std::vector<uint64_t> wc(nb * W), hdr(nb);
+    hal::d2h_rows(wc.data(), (uint8_t*)PL.arena.ptr + C->o_counters + 64 * 8, W * 8, stride, nb);
+    std::vector<double> sum(W, 0.0);
+    for (size_t i = 0; i < nb; ++i) for (size_t k = 0; k < W; ++k) sum[k] += (double)wc[i * W + k];
+    static const char* ph[] = {"prefilter", "wave-local Add", "commit", "fresh commit", "fresh setup", "workgroup Add", "nodes", "relax / ctx"};
+    const int nw = ctx->sim_block_threads / 64;
+    fprintf(stderr, "[kg sim waves] %zu simulations; cycles per simulation (work / wait at the barrier), per wave\n", nb);
+    for (int k = 0; k < 8; ++k) {
+      fprintf(stderr, "[kg sim waves] %-15s", ph[k]);
+      for (int w = 0; w < nw; ++w) fprintf(stderr, "  %8.0f / %-8.0f", sum[w * 32 + 2 * k] / nb, sum[w * 32 + 2 * k + 1] / nb);
+      fprintf(stderr, "\n");
+    }
+    for (int k = 16; k < 24; ++k) {
+      fprintf(stderr, "[kg sim waves] slot %2d        ", k);
+      for (int w = 0; w < nw; ++w) fprintf(stderr, "  %8.0f", sum[w * 32 + k] / nb);
+      fprintf(stderr, "\n");
+    }
+  }
+  if (C->dp.stats & 16) {
+    // debug (kg_set_collect_stats bit 1): where the simulations of the last batch spent their time -- 100 MHz stamps each
+    // workgroup left at kernel entry, after staging its tables and at its end
+    const size_t nb = std::min(PL.max_batch, live.size());
+    std::vector<uint64_t> st(nb * 4);
+    hal::d2h_rows(st.data(), (uint8_t*)PL.arena.ptr + C->o_counters + 8 * 8, 32, stride, nb);
+    uint64_t t0 = ~0ull, t1 = 0;
+    double sx = 0, sy = 0, sxx = 0, sxy = 0, sstage = 0;
+    for (size_t i = 0; i < nb; ++i) {
+      const uint64_t* v = &st[i * 4];
+      t0 = std::min(t0, v[0]); t1 = std::max(t1, v[2]);
+      const double x = (double)v[3], y = (v[2] - v[1]) / 100.0;
+      sx += x; sy += y; sxx += x * x; sxy += x * y; sstage += (v[1] - v[0]) / 100.0;
+    }
+    const double n = (double)nb, slope = (n * sxy - sx * sy) / std::max(1e-9, n * sxx - sx * sx), icpt = (sy - slope * sx) / n;
+    fprintf(stderr, "[kg sims] %zu simulations, first entry -> last end %.1f us; staging %.2f us mean; loop = %.2f us + %.3f us x pods (mean pods %.1f, mean loop %.1f us)\n",
+            nb, (t1 - t0) / 100.0, sstage / n, icpt, slope, sx / n, sy / n);
+    std::vector<uint64_t> starts;
+    for (size_t i = 0; i < nb; ++i) starts.push_back(st[i * 4] - t0);
+    std::sort(starts.begin(), starts.end());
+    fprintf(stderr, "[kg sims] entry times (us after the first): p10 %.1f p50 %.1f p90 %.1f last %.1f\n", starts[nb / 10] / 100.0, starts[nb / 2] / 100.0,
+            starts[nb * 9 / 10] / 100.0, starts[nb - 1] / 100.0);
+  }
   ctx->stats.device_ms_total += ms_total;
   {
     uint64_t v[4] = {0, 0, 0, 0};

@@ -40,6 +40,7 @@ constexpr int KG_EBITS = 32;    // requirement-value words of one pod staged in 
 constexpr int KG_THR_LDS = 1024;  // fit-threshold values staged in LDS
 constexpr int KG_ORD = 1024;      // in-flight NodeClaims whose scan order is kept in LDS (global memory beyond)
 constexpr int KG_MAXGP = 24;      // NodeClaims evaluated exactly per pass
+constexpr int KG_TL = 16;         // touched nodes of a simulation kept in LDS (those beyond: global list + hash)
 constexpr int KG_NTMAX = 1024;    // threads of the largest workgroup solve_block is instantiated for
 constexpr int KG_GP0 = 8;         // ... in the first pass over a chunk of the scan order
 constexpr int KG_ROWW = 64;       // requirement-value words of one claim row
@@ -181,10 +182,9 @@ struct DevProblem {
   int n_zone_vals, n_ct_vals;
   // existing nodes (scan order)
   uint32_t sparse_nodes;        // batches of simulations: a simulation keeps what it adds to existing nodes as a short list of
-                                // touched nodes (SimState::tnode ...) over the shared nreq0 / nports0 instead of its own [R][N] copy
-  const int64_t* nreq0;         // [R][N] requests already on the node before this Solve (remaining daemonset requests)
+                                // touched nodes (SimState::tnode ...) over the shared nfree0 / nports0 instead of its own [R][N] copy
+  const int64_t* nfree0;        // [R][N] what the node can still take when the Solve starts: available - (remaining daemonset) requests
   const uint64_t* nports0;      // [N] host-port ids reserved on the node by its bound pods
-  const int64_t* navail;        // [R][N]
   const uint64_t* nlab;         // [S][NW] label compat per requirement set (k_node_static)
   const uint64_t* ntol;         // [TS][NW]
   const uint16_t* ndom;         // [nspec][N] node's value id on each special key, 0xFFFF absent
@@ -195,9 +195,9 @@ struct DevProblem {
 
 // Mutable state of ONE simulation (device pointers into that simulation's arena).
 struct SimState {
-  KG_GLOBAL int64_t* nreq;      // [R][N] (dense mode: one Solve)
+  KG_GLOBAL int64_t* nfree;     // [R][N] (dense mode: one Solve) nfree0 minus what this Solve placed on the node
   KG_GLOBAL uint64_t* nports;   // [N] host-port ids reserved on the node (bit per entry of the solve's port vocabulary)
-  // sparse mode (DevProblem::sparse_nodes): nodes this simulation has put pods on -- header[6] entries
+  // sparse mode (DevProblem::sparse_nodes): nodes this simulation has put pods on (entries KG_TL.. of the list; the first KG_TL are in LDS, Shared::tl_*)
   KG_GLOBAL uint64_t* ntouch;   // [NW] bit per node: it has an entry below
   KG_GLOBAL uint32_t* tnode;    // [Cmax] node (scan position)
   KG_GLOBAL uint64_t* thash;    // [thash_mask + 1] open addressing, (node + 1) << 32 | entry, 0 = empty: node -> its entry in O(1)
@@ -272,6 +272,7 @@ struct SharedBase {
   uint32_t ffeas[4];                // wave-local evaluation (fast path): feasible rows of pass k in slot k & 3, slot (k + 1) & 3 cleared meanwhile
   unsigned long long ball[16];      // prefilter ballots of the current chunk of scan positions, one word per wave
   uint16_t wpos[16][KG_MAXGP];      // chunk positions of each wave's first survivors, in order
+  uint4 qn[2];                      // the queue entry two behind the head, staged while a pod is placed (slot = placement parity)
   PodCtx pcb[2];                    // the pod being placed / the next pod of the queue, fetched while the current one is placed
                                     // (the roles swap at every Queue.Pop: no copy)
   uint64_t offm[KG_OFFROWS][KG_TWLDS];          // offering masks [zone * n_ct + ct]
@@ -291,6 +292,11 @@ struct SharedBase {
 struct Shared : SharedBase {
   Row rows[KG_MAXGP];                    // evaluation groups of the current pass
   int32_t ntk[KG_NTMAX];                 // existing-node scan: touched entry of the node each thread found feasible (commit_node)
+  // sparse mode: the first KG_TL nodes the simulation put pods on (a single-node simulation touches a handful) -- node,
+  // requests added, host-port word.  Entries from KG_TL on live in SimState::tnode / tadd / tports / thash / ntouch.
+  uint32_t tl_node[KG_TL];
+  uint64_t tl_ports[KG_TL];
+  int64_t tl_add[KG_TL][KG_MAXR];
 };
 static_assert(sizeof(Shared) <= 80 * 1024, "two workgroups of k_simulate share a CU's 160 KB of LDS");
 
@@ -771,28 +777,40 @@ KG_HD void claim_refresh_head(const DevProblem& P, const SimState& S, const Shar
 
 // ------------------------------------------------------------------ ExistingNode.Add for node n (scan position)
 // *tk_out: (sparse mode) the node's entry in the simulation's touched list as this evaluation found it, -1 when it has none
-KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, const PodCtx& pc, uint32_t n, uint32_t* reason, int* tk_out) {
+// ntouched: entries of that list (uniform)
+KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, const PodCtx& pc, uint32_t need, uint32_t n, uint32_t ntouched, uint32_t tl_cap, uint32_t* reason, int* tk_out) {
   const Variant& v = pc.vc.v;
   const uint32_t wi = n >> 6, bi = n & 63;
+  const bool spilled = P.sparse_nodes && ntouched > tl_cap;  // some touched nodes live in global memory (tl_cap: KG_TL, or 0)
   // Every word the checks below may look at is requested before the first one is used: one round trip for the node instead
   // of one per check (each `return` below would otherwise put a wait and a branch in front of the next load).
   const uint64_t w_excl = S.excl[wi], w_tol = P.ntol[(size_t)v.tolset * P.NW + wi], w_lab = P.nlab[(size_t)v.rs * P.NW + wi];
-  const uint64_t w_touch = P.sparse_nodes ? S.ntouch[wi] : 0ull;
+  const uint64_t w_touch = spilled ? S.ntouch[wi] : 0ull;
   const uint32_t h0 = (n * 2654435761u) & S.thash_mask;
-  const uint64_t e0 = P.sparse_nodes ? S.thash[h0] : 0ull;  // the node's home slot: nearly always where its entry is
+  const uint64_t e0 = spilled ? S.thash[h0] : 0ull;  // the node's home slot: nearly always where its entry is
   const uint64_t w_ports = !P.has_ports ? 0ull : (P.sparse_nodes ? P.nports0[n] : S.nports[n]);
-  int64_t n_av[KG_MAXR], n_rq[KG_MAXR];
+  // what the node can still take of every resource the pod requests (`need` is uniform: scalar branches, no load more
+  // than the pod needs)
+  int64_t n_free[KG_MAXR];
 #pragma unroll
   for (int r = 0; r < KG_MAXR; ++r) {
-    const size_t at = (size_t)(r < P.R ? r : 0) * P.N + n;
-    n_av[r] = P.navail[at];
-    n_rq[r] = P.sparse_nodes ? P.nreq0[at] : S.nreq[at];
+    n_free[r] = 0;
+    if ((need >> r) & 1) n_free[r] = P.sparse_nodes ? P.nfree0[(size_t)r * P.N + n] : S.nfree[(size_t)r * P.N + n];
   }
-  if ((w_excl >> bi) & 1) return false;  // a candidate of this simulation: not a state node
-  if (!((w_tol >> bi) & 1)) { *reason |= 1; return false; }
+  // The verdicts of the static checks are combined before the first branch: a `return` after each would let the compiler
+  // move the loads a later check needs behind it (a second round trip).  Upstream's order decides the reason reported.
+  const bool f_excl = (w_excl >> bi) & 1;     // a candidate of this simulation: not a state node
+  const bool f_tol = !((w_tol >> bi) & 1);
+  const bool f_lab = !((w_lab >> bi) & 1);
   int tk = -1;  // sparse mode: the node's entry in the simulation's touched list
+  int64_t have[KG_MAXR];
+#pragma unroll
+  for (int r = 0; r < KG_MAXR; ++r) have[r] = 0;
+  uint64_t ports_now = w_ports;
   if (P.sparse_nodes) {
-    if ((w_touch >> bi) & 1) {
+    const uint32_t nl = ntouched < tl_cap ? ntouched : tl_cap;
+    for (uint32_t i = 0; i < nl; ++i) tk = sh.tl_node[i] == n ? (int)i : tk;  // (every lane reads the same word)
+    if (tk < 0 && ((w_touch >> bi) & 1)) {
       uint64_t e = e0;
       for (uint32_t h = h0;;) {
         if ((uint32_t)(e >> 32) == n + 1) { tk = (int)(uint32_t)e; break; }
@@ -801,23 +819,25 @@ KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, c
         e = S.thash[h];
       }
     }
-    if (P.has_ports && ((tk >= 0 ? S.tports[tk] : w_ports) & pc.vc.hp_conf)) { *reason |= 2; return false; }  // HostPortUsage.Conflicts
-    // resources first (cheap reject), as upstream does
+    // what the simulation has added to the node so far (LDS for the first KG_TL touched nodes; the rest: one round trip)
+    if (tk >= (int)tl_cap) {
 #pragma unroll
-    for (int r = 0; r < KG_MAXR; ++r) {
-      if (r >= P.R || pc.preq[r] == 0) continue;
-      const int64_t have = n_rq[r] + (tk >= 0 ? S.tadd[(size_t)r * P.Cmax + tk] : 0);
-      if (have + pc.preq[r] > n_av[r]) { *reason |= 64; return false; }
-    }
-  } else {
-    if (P.has_ports && (w_ports & pc.vc.hp_conf)) { *reason |= 2; return false; }  // HostPortUsage.Conflicts
-    // resources first (cheap reject), as upstream does
+      for (int r = 0; r < KG_MAXR; ++r) if ((need >> r) & 1) have[r] = S.tadd[(size_t)r * P.Cmax + tk];
+      if (P.has_ports) ports_now = S.tports[tk];
+    } else if (tk >= 0) {
 #pragma unroll
-    for (int r = 0; r < KG_MAXR; ++r) {
-      if (r < P.R && pc.preq[r] != 0 && n_rq[r] + pc.preq[r] > n_av[r]) { *reason |= 64; return false; }
+      for (int r = 0; r < KG_MAXR; ++r) have[r] = sh.tl_add[tk][r];
+      if (P.has_ports) ports_now = sh.tl_ports[tk];
     }
   }
-  if (!((w_lab >> bi) & 1)) { *reason |= 2; return false; }
+  const bool f_ports = P.has_ports && (ports_now & pc.vc.hp_conf);  // HostPortUsage.Conflicts
+  bool f_res = false;  // resources before labels (cheap reject), as upstream does
+#pragma unroll
+  for (int r = 0; r < KG_MAXR; ++r) f_res = f_res || (((need >> r) & 1) && have[r] + pc.preq[r] > n_free[r]);
+  if (f_excl || f_tol || f_ports || f_res || f_lab) {
+    *reason |= f_excl ? 0u : f_tol ? 1u : f_ports ? 2u : f_res ? 64u : 2u;
+    return false;
+  }
   for (uint32_t li = 0; li < pc.vc.nlist; ++li) {
     const ListEntry le = pc.vc.lst[li].le;
     const Group g = pc.vc.lst[li].g;
@@ -838,24 +858,34 @@ KG_HD bool eval_node(const DevProblem& P, const SimState& S, const Shared& sh, c
 
 // ExistingNode.Add's state update for the node the scan chose (one thread).  Nothing is evaluated again: the state has not
 // changed since the scan.  tk: the node's touched entry as its evaluation found it (-1: none yet, it becomes entry
-// `ntouched`, the simulation's count so far -- the caller keeps that count; header[6] is only written for k_sim_gather).
-KG_HD void commit_node(const DevProblem& P, const SimState& S, const PodCtx& pc, uint32_t n, int tk, uint32_t ntouched) {
+// `ntouched`, the simulation's count so far, which the caller keeps).
+KG_HD void commit_node(const DevProblem& P, const SimState& S, Shared& sh, const PodCtx& pc, uint32_t n, int tk, uint32_t ntouched, uint32_t tl_cap) {
   const Variant& v = pc.vc.v;
   const uint32_t wi = n >> 6, bi = n & 63;
   if (P.sparse_nodes) {
     if (tk < 0) {  // (the list grows by at most one entry per placed pod, Cmax in all)
       tk = (int)ntouched;
-      uint32_t h = (n * 2654435761u) & S.thash_mask;
-      uint64_t e = S.thash[h];
-      const uint64_t w_touch = S.ntouch[wi];
       const uint64_t w_ports = P.has_ports ? P.nports0[n] : 0ull;
-      while (e != 0) { h = (h + 1) & S.thash_mask; e = S.thash[h]; }
-      S.thash[h] = ((uint64_t)(n + 1) << 32) | (uint32_t)tk;
-      S.header[6] = (uint32_t)tk + 1;
-      S.tnode[tk] = n;
-      S.ntouch[wi] = w_touch | (1ull << bi);
-      for (int r = 0; r < P.R; ++r) S.tadd[(size_t)r * P.Cmax + tk] = pc.preq[r];
-      S.tports[tk] = w_ports | (P.has_ports ? pc.vc.hp_use : 0ull);
+      if (tk < (int)tl_cap) {
+        sh.tl_node[tk] = n;
+#pragma unroll
+        for (int r = 0; r < KG_MAXR; ++r) sh.tl_add[tk][r] = r < P.R ? pc.preq[r] : 0;
+        sh.tl_ports[tk] = w_ports | (P.has_ports ? pc.vc.hp_use : 0ull);
+      } else {
+        uint32_t h = (n * 2654435761u) & S.thash_mask;
+        uint64_t e = S.thash[h];
+        const uint64_t w_touch = S.ntouch[wi];
+        while (e != 0) { h = (h + 1) & S.thash_mask; e = S.thash[h]; }
+        S.thash[h] = ((uint64_t)(n + 1) << 32) | (uint32_t)tk;
+        S.tnode[tk] = n;
+        S.ntouch[wi] = w_touch | (1ull << bi);
+        for (int r = 0; r < P.R; ++r) S.tadd[(size_t)r * P.Cmax + tk] = pc.preq[r];
+        S.tports[tk] = w_ports | (P.has_ports ? pc.vc.hp_use : 0ull);
+      }
+    } else if (tk < (int)tl_cap) {
+#pragma unroll
+      for (int r = 0; r < KG_MAXR; ++r) if (r < P.R) sh.tl_add[tk][r] += pc.preq[r];
+      if (P.has_ports) sh.tl_ports[tk] |= pc.vc.hp_use;
     } else {
       int64_t have[KG_MAXR];
 #pragma unroll
@@ -865,7 +895,7 @@ KG_HD void commit_node(const DevProblem& P, const SimState& S, const PodCtx& pc,
       if (P.has_ports) S.tports[tk] |= pc.vc.hp_use;
     }
   } else {
-    for (int r = 0; r < P.R; ++r) if (pc.preq[r] != 0) S.nreq[(size_t)r * P.N + n] += pc.preq[r];
+    for (int r = 0; r < P.R; ++r) if (pc.preq[r] != 0) S.nfree[(size_t)r * P.N + n] -= pc.preq[r];
     if (P.has_ports) S.nports[n] |= pc.vc.hp_use;
   }
   for (uint32_t li = 0; li < v.record_cnt; ++li) {
@@ -907,9 +937,51 @@ KG_HD void ord_set(const SimState& S, Shared& sh, const DevProblem& P, bool lds,
   if (lds) sh.ord[buf][p] = v; else S.ordg[(size_t)buf * P.Cmax + p] = v;
 }
 
+// The contiguous image (k_pod_ctx) with at least one thread per word: the word is requested first and stored after other
+// work (the existing-node scan puts every load of a placement in front of its first wait).
+template <int NT>
+KG_HD bool ctx_word_per_thread(const DevProblem& P) { return P.TW <= KG_TWLDS && (size_t)NT >= sizeof(PodCtx) / 8; }
+KG_HD uint64_t ctx_word_load(const DevProblem& P, int tid, uint32_t pod, uint32_t variant) {
+  // ONE load per thread whatever the word (a load per case would share its destination register with the others and the
+  // compiler waits before overwriting a register a load is still due in); PodCtx::need is not filled: solve_block derives
+  // it from the requests
+  const uint32_t i = (uint32_t)tid < sizeof(PodCtx) / 8 ? (uint32_t)tid : (uint32_t)KG_MAXR;
+  const uint64_t* src = ((const uint64_t*)(P.pctx + variant)) + i;
+  if (i < (uint32_t)KG_MAXR) src = (const uint64_t*)(P.preq + (size_t)pod * P.R + ((int)i < P.R ? i : 0));
+  return *src;  // (ctx_word_store zeroes the request words beyond the problem's resources: no use of the value here)
+}
+KG_HD void ctx_word_store(const DevProblem& P, PodCtx& nx, int tid, uint64_t v) {
+  if (tid < KG_MAXR && tid >= P.R) v = 0;
+  if ((uint32_t)tid < sizeof(PodCtx) / 8) ((uint64_t*)&nx)[tid] = v;
+}
+
 // one Queue.Pop's worth of pod context, global -> the buffer of the next pod (each thread moves its share; needs a barrier afterwards)
 template <int NT>
 KG_HD void ctx_fetch(const DevProblem& P, PodCtx& nx, int tid, uint32_t pod, uint32_t variant) {
+  if (P.TW <= KG_TWLDS) {
+    // the contiguous image k_pod_ctx built (struct PodCtx, requests left zero): one level of loads, none depends on another
+    static_assert(offsetof(PodCtx, preq) == 0 && offsetof(PodCtx, need) == KG_MAXR * 8, "the words the pod (not its variant) decides come first");
+    const uint64_t* img = (const uint64_t*)(P.pctx + variant);
+    uint64_t* dst = (uint64_t*)&nx;
+    for (uint32_t i = (uint32_t)tid; i < sizeof(PodCtx) / 8; i += NT) {
+      uint64_t v;
+      if (i < (uint32_t)KG_MAXR) {
+        v = (int)i < P.R ? (uint64_t)P.preq[(size_t)pod * P.R + i] : 0;
+      } else if (i == (uint32_t)KG_MAXR) {
+        int64_t q[KG_MAXR];
+#pragma unroll
+        for (int r = 0; r < KG_MAXR; ++r) q[r] = P.preq[(size_t)pod * P.R + (r < P.R ? r : 0)];
+        uint32_t nd = 0;
+#pragma unroll
+        for (int r = 0; r < KG_MAXR; ++r) if (r < P.R && q[r] != 0) nd |= 1u << r;
+        v = nd;
+      } else {
+        v = img[i];
+      }
+      dst[i] = v;
+    }
+    return;
+  }
   const uint64_t* src = (const uint64_t*)(P.vctx + variant);
   uint64_t* dst = (uint64_t*)&nx.vc;
   for (uint32_t i = tid; i < sizeof(VariantCtx) / 8; i += NT) dst[i] = src[i];
@@ -918,8 +990,12 @@ KG_HD void ctx_fetch(const DevProblem& P, PodCtx& nx, int tid, uint32_t pod, uin
     nx.preq[r] = r < P.R ? P.preq[(size_t)pod * P.R + r] : 0;
   }
   if (tid == NT - KG_MAXR - 2) {
+    int64_t q[KG_MAXR];
+#pragma unroll
+    for (int r = 0; r < KG_MAXR; ++r) q[r] = P.preq[(size_t)pod * P.R + (r < P.R ? r : 0)];
     uint32_t nd = 0;
-    for (int r = 0; r < P.R; ++r) if (P.preq[(size_t)pod * P.R + r] != 0) nd |= 1u << r;
+#pragma unroll
+    for (int r = 0; r < KG_MAXR; ++r) if (r < P.R && q[r] != 0) nd |= 1u << r;
     nx.need = nd;
   }
   if (tid == NT - KG_MAXR - 1) nx.tolw = P.tol_tmpl[P.vctx[variant].v.tolset];
@@ -1272,18 +1348,25 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
   const uint32_t TWP = (uint32_t)P.TWP;      // threads per evaluation group (power of two >= max(TW, 16))
   const uint32_t GP = (NT / TWP) < (uint32_t)KG_MAXGP ? (NT / TWP) : (uint32_t)KG_MAXGP;  // claims evaluated per pass
   static_assert(NT % 64 == 0 && NT / 64 <= 16 && NT <= KG_NTMAX, "one ballot word per wave");
+  const bool STAMPS = (P.stats & 16) != 0;  // debug: the simulation leaves 100 MHz time stamps in counters[8..10]
+  if (STAMPS) { KG_FOR_THREADS(tid, NT) { if (tid == 0) S.counters[8] = now_ticks(); } }
   stage_tables<NT>(P, sh);
+  if (STAMPS) { KG_FOR_THREADS(tid, NT) { if (tid == 0) { S.counters[9] = now_ticks(); S.counters[11] = n_queue; } } }
   const uint32_t QCAP = S.qcap;
   // ---- uniform state of the Solve
   uint32_t qhead = 0, qlen = n_queue, epoch = 1;   // Queue ring; epoch/len implement lastLen
   uint32_t nclaims = 0, seq = 0;                   // in-flight NodeClaims, placement steps
   uint32_t ntouched = 0;                           // sparse mode: entries of the simulation's touched-node list
+  // ... the first tl_cap of them in LDS.  A simulation with many pods (a multi-node prefix) touches hundreds of nodes: it
+  // would pay the LDS search on every node and still go to the global list, so it keeps all of them there.
+  const uint32_t tl_cap = n_queue <= 4u * KG_TL ? (uint32_t)KG_TL : 0u;
   uint32_t ob = 0;                                 // current buffer of the scan order
   bool ord_lds = true;                             // scan order still in LDS
   uint32_t last_c = KG_NOIDX, last_npods = 0, last_stamp = 0, last_new = 0;  // the one claim touched since the reference's last sort
   bool have_next = false, ctx_ready = false;       // next queue entry / its context already fetched
   uint4 qe_next;
   qe_next.x = qe_next.y = qe_next.z = qe_next.w = 0;
+  bool q2_ready = false;                           // the entry two behind the head is in sh.qn (staged one placement early)
   uint32_t passno = 0;
   uint32_t cur = 0, placement = 0;                 // buffer of sh.pcb that holds the pod being placed; placements so far
   uint32_t fpass = 0, endk_fast = 0;                // wave-local passes so far; the winner's group end when such a pass found it
@@ -1296,7 +1379,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     qe.x = KG_UNI(qe.x); qe.y = KG_UNI(qe.y); qe.z = KG_UNI(qe.z); qe.w = KG_UNI(qe.w);
     if (qe.z == epoch && qe.w == qlen) break;  // every remaining pod failed with the queue at this length: done
     const uint32_t pod = qe.x, variant = qe.y;
-    qhead = (qhead + 1) % QCAP;
+    qhead = qhead + 1 == QCAP ? 0 : qhead + 1;  // (a compare instead of a division: this is per placement)
     qlen -= 1;
     // ---- pod context: fetched during the previous placement into the other buffer, or now; the buffers swap roles
     if (!ctx_ready) {
@@ -1310,25 +1393,50 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     const uint32_t bslot = placement & 1;   // sh.best2 slot of this placement; the other one is reset meanwhile
     KG_FOR_THREADS(tid, NT) { if (tid == 0) sh.reason = 0; }  // (only thread 0 ever touches it)
     // the entry behind the head is settled (a push lands behind it) when at least one pod is left
-    have_next = qlen >= 1;
-    if (have_next) qe_next = ((const KG_GLOBAL uint4*)S.queue)[qhead];  // (made uniform when it is popped)
+    // ... and so is the one behind that when two are left: it is requested together with the other loads of this
+    // placement and parked in LDS, so the next placement's context fetch does not wait for the queue first (and no load
+    // stays in flight across the loop's back edge, where the compiler would wait for every outstanding one)
+    if (q2_ready) { have_next = true; qe_next = sh.qn[bslot ^ 1]; }  // (staged during the previous placement)
+    else {
+      have_next = qlen >= 1;
+      if (have_next) qe_next = ((const KG_GLOBAL uint4*)S.queue)[qhead];  // (made uniform when it is popped)
+    }
+    q2_ready = false;
+    const bool want_q2 = qlen >= 2;                    // staged together with the context prefetch
+    const uint32_t q2_pos = qhead + 1 == QCAP ? 0 : qhead + 1;
     bool want_pf = have_next;
     ctx_ready = false;
-    const uint32_t need = KG_UNI(pc.need);
+    uint32_t need = 0;  // bit per active resource the pod requests (uniform)
+#pragma unroll
+    for (int r = 0; r < KG_MAXR; ++r) need |= (pc.preq[r] != 0 ? 1u : 0u) << r;
+    need = KG_UNI(need);
     KG_T(0);
     // ---- existing nodes, first feasible in scan order
     for (uint32_t base = 0; base < (uint32_t)P.N; base += NT) {
+      KG_W(16);
+      const bool pf_word = want_pf && ctx_word_per_thread<NT>(P);
       KG_FOR_THREADS(tid, NT) {
+        // every load of the placement is requested before the first wait: the next pod's context word, the queue entry two
+        // ahead (the last thread, which has no context word), then the node's words inside eval_node
+        uint64_t cword = 0;
+        uint4 q2;
+        q2.x = q2.y = q2.z = q2.w = 0;
+        if (pf_word) cword = ctx_word_load(P, tid, qe_next.x, qe_next.y);
+        if (want_pf && want_q2 && tid == NT - 1) q2 = ((const KG_GLOBAL uint4*)S.queue)[q2_pos];
         const uint32_t n = base + tid;
         if (n < (uint32_t)P.N) {
           uint32_t reason = 0;
           int tk = -1;
-          if (eval_node(P, S, sh, pc, n, &reason, &tk)) { sh.ntk[tid] = tk; atomic_min_u32(&sh.best2[bslot], n); }
+          if (eval_node(P, S, sh, pc, need, n, ntouched, tl_cap, &reason, &tk)) { sh.ntk[tid] = tk; atomic_min_u32(&sh.best2[bslot], n); }
         }
+        KG_W(17);
         if (tid == 0) sh.best2[bslot ^ 1] = KG_NOIDX;  // (last read one placement ago)
-        if (want_pf) ctx_fetch<NT>(P, nx, tid, qe_next.x, qe_next.y);
+        if (pf_word) ctx_word_store(P, nx, tid, cword);
+        else if (want_pf) ctx_fetch<NT>(P, nx, tid, qe_next.x, qe_next.y);
+        if (want_pf && want_q2 && tid == NT - 1) sh.qn[bslot] = q2;
+        KG_W(18);
       }
-      if (want_pf) { want_pf = false; ctx_ready = true; }
+      if (want_pf) { want_pf = false; ctx_ready = true; q2_ready = want_q2; }
       KG_SYNCW(6);
       if (KG_UNI(sh.best2[bslot]) != KG_NOIDX) break;
     }
@@ -1338,12 +1446,13 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
       KG_FOR_THREADS(tid, NT) {
         if (tid == 0) {
           const uint32_t bn = bn_u;
-          commit_node(P, S, pc, bn, tk_u, ntouched);
+          commit_node(P, S, sh, pc, bn, tk_u, ntouched, tl_cap);
           S.pod_kind[pod_row(S, pod)] = 1;
           S.pod_index[pod_row(S, pod)] = (int32_t)bn;
           if (STATS) S.counters[0] += bn + 1;
         }
       }
+      KG_W(19);
       if (P.sparse_nodes && tk_u < 0) ntouched += 1;
       KG_SYNCW(6);
       KG_T(1);
@@ -1413,10 +1522,13 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
           const uint32_t rank = wave_ballot_store(sh.ball, tid, ok);
           if (ok && rank < (uint32_t)KG_MAXGP) sh.wpos[tid >> 6][rank] = (uint16_t)tid;
           KG_W(18);
-          if (want_pf) ctx_fetch<NT>(P, nx, tid, qe_next.x, qe_next.y);
+          if (want_pf) {
+            ctx_fetch<NT>(P, nx, tid, qe_next.x, qe_next.y);
+            if (want_q2 && tid == NT - 1) sh.qn[bslot] = ((const KG_GLOBAL uint4*)S.queue)[q2_pos];
+          }
           KG_ST(2);
         }
-        if (want_pf) { want_pf = false; ctx_ready = true; }
+        if (want_pf) { want_pf = false; ctx_ready = true; q2_ready = want_q2; }
         KG_SYNCW(0);
         { KG_FOR_THREADS(tid, NT) { KG_ST(3); } }
 #pragma unroll
@@ -1791,18 +1903,19 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
           qn.y = variant;
           qn.z = epoch; qn.w = qlen + 1;  // lastLen[pod] = len(queue) after the push
         }
-        ((KG_GLOBAL uint4*)S.queue)[(qhead + qlen) % QCAP] = qn;
+        ((KG_GLOBAL uint4*)S.queue)[qhead + qlen >= QCAP ? qhead + qlen - QCAP : qhead + qlen] = qn;
       }
     }
     qlen += 1;
     if (vnext >= 0) epoch += 1;  // lastLen = {} on a relaxed push
     // the pushed entry is the head when nothing else is queued: it was not there when the next entry was fetched
-    if (qlen == 1) { have_next = false; ctx_ready = false; }
+    if (qlen == 1) { have_next = false; q2_ready = false; ctx_ready = false; }
     KG_SYNCW(7);
     KG_T(9);
   }
   KG_FOR_THREADS(tid, NT) {
     if (tid == 0) {
+      if (STAMPS) S.counters[10] = now_ticks();
       S.header[0] = nclaims;
       S.header[2] = last_c; S.header[3] = last_npods; S.header[4] = last_stamp; S.header[5] = last_new;
     }

@@ -12,7 +12,7 @@ for p in pods:
 prob = Problem(types, pods, [wl.default_nodepool()], nodes=nodes, bound=bound[12:])
 L = lib.Library()
 hcat = L.catalog_upload(prob.cat)
-for mode in (0, 0, 2):
+for mode in (0, 0, 2, 32):
     L.set_collect_stats(mode)
     rb = prob.run_library(L, hcat)
     sys.stderr.flush()
