@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
-PMC_FILE = os.path.join("profiles", "r02e_pmc.json")
+PMC_FILE = os.path.join("profiles", "r02f_pmc.json")
 
 
 def pmc_traffic(kernel, default_workload):

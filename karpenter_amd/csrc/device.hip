@@ -61,15 +61,24 @@ __global__ void __launch_bounds__(NT) k_solve(DevProblem Pin, const SimState* si
 
 // k_simulate: the same solve loop, one workgroup per consolidation simulation (a kernel of its own so that profiles keep
 // the one persistent Solve and the batches of simulations apart)
-// (second launch bound: two waves per SIMD, i.e. two 256-thread workgroups per CU -- the register budget that goes with it)
-template <int NT, bool DBG>
-__global__ void __launch_bounds__(NT, 2) k_simulate(DevProblem Pin, const SimState* sims, const uint32_t* nqueue) {
-  __shared__ Shared sh;
+// Its LDS is dynamic: a simulation rarely opens NodeClaims, so it gets sim_gp_cap(NT) evaluation groups instead of
+// KG_MAXGP (DevProblem::gp_cap tells solve_block), 52 KB instead of 74, and THREE 256-thread workgroups share a CU; the
+// second launch bound is the register budget that goes with it (168 per thread).  Simulations do not contend with each
+// other (tools/gpu_sim_sweep.py): each is one chain of dependent placements, so residency is throughput.
+constexpr uint32_t sim_gp_cap(int nt) { return (uint32_t)(nt / 64 > KG_GPMIN ? nt / 64 : KG_GPMIN); }
+constexpr size_t sim_lds_bytes(int nt) { return sizeof(Shared) - (size_t)(KG_MAXGP - sim_gp_cap(nt)) * sizeof(Row); }
+static_assert(sim_lds_bytes(256) * 3 <= 160 * 1024, "three workgroups of k_simulate share a CU's 160 KB of LDS");
+static_assert(sim_lds_bytes(512) <= 64 * 1024, "dynamic LDS without an opt-in attribute");
+extern __shared__ __align__(16) unsigned char sim_lds[];
+// OCC: workgroups per CU the register budget allows.  3 (168 registers, a few dozen spilled) for a batch that fills the
+// chip more than twice over; 2 (256 registers, none spilled) for a small batch, whose time is its longest simulation.
+template <int NT, bool DBG, int OCC>
+__global__ void __launch_bounds__(NT, OCC) k_simulate(DevProblem Pin, const SimState* sims, const uint32_t* nqueue) {
+  Shared& sh = *reinterpret_cast<Shared*>(sim_lds);
   const DevProblem& P = Pin;
   const SimState S = sims[blockIdx.x];
   solve_block<NT, DBG>(P, S, sh, nqueue[blockIdx.x]);
 }
-
 // k_solve_wave: one WAVE = one Scheduler.Solve (solve_wave.hpp: batches without topology groups / existing nodes / minValues)
 template <bool DBG>
 __global__ void __launch_bounds__(64) k_solve_wave(DevProblem Pin, const SimState* sims, const uint32_t* nqueue) {
@@ -240,6 +249,15 @@ struct Timer {
   }
 };
 
+template <int NT, bool DBG>
+static void launch_k_simulate(DevProblem P, const SimState* sims, int nsims, const uint32_t* nqueue) {
+  P.gp_cap = sim_gp_cap(NT);
+  if (NT == 256 && !DBG && nsims > 2 * 256)  // (256 CUs: more simulations than two per CU)
+    hipLaunchKernelGGL((k_simulate<NT, DBG, (NT == 256 && !DBG) ? 3 : 1>), dim3(nsims), dim3(NT), sim_lds_bytes(NT), t_stream, P, sims, nqueue);
+  else
+    hipLaunchKernelGGL((k_simulate<NT, DBG, (NT == 256 && !DBG) ? 2 : 1>), dim3(nsims), dim3(NT), sim_lds_bytes(NT), t_stream, P, sims, nqueue);
+}
+
 void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms) {
   Timer t("kg prepass (k_type_filter, k_node_static, k_pod_mask, k_pod_ctx)");
   const uint32_t total = X.E * (uint32_t)P.TW;
@@ -256,8 +274,8 @@ void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms) {
 void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int block, float* ms, bool batch) {
   Timer t("kg solve (k_solve / k_simulate)");
   if (batch) {
-    if (block >= 512) hipLaunchKernelGGL((k_simulate<512, false>), dim3(nsims), dim3(512), 0, t_stream, P, sims, nqueue);
-    else hipLaunchKernelGGL((k_simulate<256, false>), dim3(nsims), dim3(256), 0, t_stream, P, sims, nqueue);
+    if (block >= 512) launch_k_simulate<512, false>(P, sims, nsims, nqueue);
+    else launch_k_simulate<256, false>(P, sims, nsims, nqueue);
     ck(hipGetLastError(), "simulate launch");
     *ms = t.stop();
     return;
@@ -302,9 +320,9 @@ void launch_sim_round(const DevProblem& P, const SimBatch& B, const SimState* si
   ck(hipEventRecord(ev[0], t_stream), "record");
   hipLaunchKernelGGL(k_sim_init, dim3(B.nsims), dim3(256), 0, t_stream, P, B);
   ck(hipEventRecord(ev[1], t_stream), "record");
-  if (P.stats & 8) hipLaunchKernelGGL((k_simulate<256, true>), dim3(B.nsims), dim3(256), 0, t_stream, P, sims, B.nqueue);  // (debug: per-wave cycle accounting)
-  else if (block >= 512) hipLaunchKernelGGL((k_simulate<512, false>), dim3(B.nsims), dim3(512), 0, t_stream, P, sims, B.nqueue);
-  else hipLaunchKernelGGL((k_simulate<256, false>), dim3(B.nsims), dim3(256), 0, t_stream, P, sims, B.nqueue);
+  if (P.stats & 8) launch_k_simulate<256, true>(P, sims, B.nsims, B.nqueue);  // (debug: per-wave cycle accounting)
+  else if (block >= 512) launch_k_simulate<512, false>(P, sims, B.nsims, B.nqueue);
+  else launch_k_simulate<256, false>(P, sims, B.nsims, B.nqueue);
   ck(hipEventRecord(ev[2], t_stream), "record");
   hipLaunchKernelGGL(k_sim_gather, dim3(B.nsims), dim3(64), 0, t_stream, P, B, sims);
   ck(hipEventRecord(ev[3], t_stream), "record");

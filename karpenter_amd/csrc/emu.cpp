@@ -47,8 +47,10 @@ void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms) {
   *ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
-void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int block, float* ms, bool) {
+void launch_solve(const DevProblem& Pin, const SimState* sims, int nsims, const uint32_t* nqueue, int block, float* ms, bool batch) {
   auto t0 = std::chrono::steady_clock::now();
+  DevProblem P = Pin;
+  if (batch) P.gp_cap = (uint32_t)std::max(block / 64, KG_GPMIN);  // (what the device's k_simulate launch gives a simulation)
   std::unique_ptr<Shared> shp(new Shared());  // (the workgroup's LDS; per call: contexts run on several threads at once)
   Shared& sh = *shp;
   for (int i = 0; i < nsims; ++i) {

@@ -1388,6 +1388,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   D.cthr_val = (const int64_t*)cptr(CT.o_cthr_val); D.cthr_mask = (const uint64_t*)cptr(CT.o_cthr_mask); D.valid_types = (const uint64_t*)cptr(CT.o_valid);
   D.cap = (const int64_t*)cptr(CT.o_cap); D.alloc = (const int64_t*)cptr(CT.o_alloc); D.offmask = (const uint64_t*)cptr(CT.o_offmask); D.zone_zid = (const uint8_t*)cptr(CT.o_zone_zid);
   D.n_zone_vals = (int)CT.n_zone_vals; D.n_ct_vals = (int)CT.n_ct_vals;
+  D.gp_cap = KG_MAXGP;  // (launch_sim_round lowers it for the batch kernel)
   D.sparse_nodes = sim_mode ? 1u : 0u; D.nfree0 = (const int64_t*)dptr(o_nfree0); D.nports0 = (const uint64_t*)dptr(o_nports0);
   D.nlab = (const uint64_t*)dptr(o_nlab); D.ntol = (const uint64_t*)dptr(o_ntol);
   D.ndom = (const uint16_t*)dptr(o_ndom); D.groups = (const Group*)dptr(o_groups); D.filters = (const uint32_t*)dptr(o_filters);

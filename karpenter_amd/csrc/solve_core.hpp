@@ -181,6 +181,7 @@ struct DevProblem {
   const uint8_t* zone_zid;      // [64] zone value id -> zone-id value id, 0xFF none
   int n_zone_vals, n_ct_vals;
   // existing nodes (scan order)
+  uint32_t gp_cap;              // evaluation groups (Shared::rows) the launch has LDS for: KG_MAXGP, or fewer for k_simulate
   uint32_t sparse_nodes;        // batches of simulations: a simulation keeps what it adds to existing nodes as a short list of
                                 // touched nodes (SimState::tnode ...) over the shared nfree0 / nports0 instead of its own [R][N] copy
   const int64_t* nfree0;        // [R][N] what the node can still take when the Solve starts: available - (remaining daemonset) requests
@@ -290,14 +291,20 @@ struct SharedBase {
 // ... plus the workgroup kernel's evaluation groups (the single-wave kernel keeps the claim row in registers and spends
 // the LDS on its prefilter records instead)
 struct Shared : SharedBase {
-  Row rows[KG_MAXGP];                    // evaluation groups of the current pass
-  int32_t ntk[KG_NTMAX];                 // existing-node scan: touched entry of the node each thread found feasible (commit_node)
   // sparse mode: the first KG_TL nodes the simulation put pods on (a single-node simulation touches a handful) -- node,
   // requests added, host-port word.  Entries from KG_TL on live in SimState::tnode / tadd / tports / thash / ntouch.
   uint32_t tl_node[KG_TL];
   uint64_t tl_ports[KG_TL];
   int64_t tl_add[KG_TL][KG_MAXR];
+  // evaluation groups of the current pass.  LAST member: k_simulate allocates only DevProblem::gp_cap of them (dynamic
+  // LDS), which is what lets three of its workgroups share a CU.
+  Row rows[KG_MAXGP];
 };
+// existing-node scan: the touched entry of the node each thread found feasible, read by commit_node after the barrier.
+// It lives in the memory of the evaluation groups: the node phase and the NodeClaim phases of a placement never overlap.
+KG_HD int32_t* scan_ntk(Shared& sh) { return (int32_t*)(void*)sh.rows; }
+constexpr int KG_GPMIN = 4;        // evaluation groups a workgroup needs at least (one per wave of 256 threads; >= NT * 4 bytes for scan_ntk)
+static_assert(sizeof(Row) * KG_GPMIN >= sizeof(int32_t) * KG_NTMAX, "scan_ntk fits the smallest allocation of rows");
 static_assert(sizeof(Shared) <= 80 * 1024, "two workgroups of k_simulate share a CU's 160 KB of LDS");
 
 
@@ -1346,7 +1353,8 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
 #endif
 #define KG_SYNCW(ph) do { KG_W(2 * (ph)); KG_SYNC(); KG_W(2 * (ph) + 1); } while (0)
   const uint32_t TWP = (uint32_t)P.TWP;      // threads per evaluation group (power of two >= max(TW, 16))
-  const uint32_t GP = (NT / TWP) < (uint32_t)KG_MAXGP ? (NT / TWP) : (uint32_t)KG_MAXGP;  // claims evaluated per pass
+  const uint32_t GP0_ = (NT / TWP) < (uint32_t)KG_MAXGP ? (NT / TWP) : (uint32_t)KG_MAXGP;
+  const uint32_t GP = GP0_ < P.gp_cap ? GP0_ : P.gp_cap;  // claims evaluated per pass (gp_cap: rows this launch has LDS for)
   static_assert(NT % 64 == 0 && NT / 64 <= 16 && NT <= KG_NTMAX, "one ballot word per wave");
   const bool STAMPS = (P.stats & 16) != 0;  // debug: the simulation leaves 100 MHz time stamps in counters[8..10]
   if (STAMPS) { KG_FOR_THREADS(tid, NT) { if (tid == 0) S.counters[8] = now_ticks(); } }
@@ -1427,7 +1435,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
         if (n < (uint32_t)P.N) {
           uint32_t reason = 0;
           int tk = -1;
-          if (eval_node(P, S, sh, pc, need, n, ntouched, tl_cap, &reason, &tk)) { sh.ntk[tid] = tk; atomic_min_u32(&sh.best2[bslot], n); }
+          if (eval_node(P, S, sh, pc, need, n, ntouched, tl_cap, &reason, &tk)) { scan_ntk(sh)[tid] = tk; atomic_min_u32(&sh.best2[bslot], n); }
         }
         KG_W(17);
         if (tid == 0) sh.best2[bslot ^ 1] = KG_NOIDX;  // (last read one placement ago)
@@ -1442,7 +1450,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     }
     if (P.N > 0 && KG_UNI(sh.best2[bslot]) != KG_NOIDX) {
       const uint32_t bn_u = KG_UNI(sh.best2[bslot]);
-      const int tk_u = (int)KG_UNI((uint32_t)sh.ntk[bn_u % NT]);  // (chunks start at multiples of NT: the thread that evaluated it)
+      const int tk_u = (int)KG_UNI((uint32_t)scan_ntk(sh)[bn_u % NT]);  // (chunks start at multiples of NT: the thread that evaluated it)
       KG_FOR_THREADS(tid, NT) {
         if (tid == 0) {
           const uint32_t bn = bn_u;
