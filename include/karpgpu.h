@@ -391,7 +391,9 @@ int32_t kg_stats_get(kg_ctx* ctx, kg_stats* out);
  * the counters off, a Solve without topology groups, existing nodes and minValues NodePools is served by the single-wave
  * kernel (kg_stats.wave_solves counts them), every other one by the workgroup kernel: same results.  The other bits are
  * debugging aids: 2 = phase timers to stderr, 4 / 8 = 1024 / 512 threads for the workgroup kernel, 16 = never use the
- * wave-local / single-wave paths, 32 = per-wave cycle accounting to stderr. */
+ * wave-local / single-wave paths, 32 = per-wave cycle accounting to stderr.  Consolidation rounds honour 2 (every simulation
+ * leaves time stamps; staging time and a per-pod fit of the batch go to stderr) and 32 (a debug instantiation of the batch
+ * kernel, cycles per phase and wave summed over the batch); set them before the first round on a snapshot (plans are cached). */
 int32_t kg_set_collect_stats(kg_ctx* ctx, int32_t enabled);
 /* "hip-gfx950" for the product library */
 const char* kg_backend(void);
