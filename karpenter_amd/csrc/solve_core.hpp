@@ -305,7 +305,7 @@ struct Shared : SharedBase {
 KG_HD int32_t* scan_ntk(Shared& sh) { return (int32_t*)(void*)sh.rows; }
 constexpr int KG_GPMIN = 4;        // evaluation groups a workgroup needs at least (one per wave of 256 threads; >= NT * 4 bytes for scan_ntk)
 static_assert(sizeof(Row) * KG_GPMIN >= sizeof(int32_t) * KG_NTMAX, "scan_ntk fits the smallest allocation of rows");
-static_assert(sizeof(Shared) <= 80 * 1024, "two workgroups of k_simulate share a CU's 160 KB of LDS");
+static_assert(sizeof(Shared) <= 80 * 1024, "two workgroups of k_solve fit a CU's 160 KB of LDS (k_simulate allocates less: device.hip)");
 
 
 // ------------------------------------------------------------------ requirement algebra
