@@ -2574,7 +2574,8 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
     double sx = 0, sy = 0, sxx = 0, sxy = 0, sstage = 0;
     for (size_t i = 0; i < nb; ++i) {
       const uint64_t* v = &st[i * 4];
-      t0 = std::min(t0, v[0]); t1 = std::max(t1, v[2]);
+      if (v[0]) t0 = std::min(t0, v[0]);  // (a slot the batch did not run keeps zeros)
+      t1 = std::max(t1, v[2]);
       const double x = (double)v[3], y = (v[2] - v[1]) / 100.0;
       sx += x; sy += y; sxx += x * x; sxy += x * y; sstage += (v[1] - v[0]) / 100.0;
     }
@@ -2582,7 +2583,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
     fprintf(stderr, "[kg sims] %zu simulations, first entry -> last end %.1f us; staging %.2f us mean; loop = %.2f us + %.3f us x pods (mean pods %.1f, mean loop %.1f us)\n",
             nb, (t1 - t0) / 100.0, sstage / n, icpt, slope, sx / n, sy / n);
     std::vector<uint64_t> starts;
-    for (size_t i = 0; i < nb; ++i) starts.push_back(st[i * 4] - t0);
+    for (size_t i = 0; i < nb; ++i) starts.push_back(st[i * 4] ? st[i * 4] - t0 : 0);
     std::sort(starts.begin(), starts.end());
     fprintf(stderr, "[kg sims] entry times (us after the first): p10 %.1f p50 %.1f p90 %.1f last %.1f\n", starts[nb / 10] / 100.0, starts[nb / 2] / 100.0,
             starts[nb * 9 / 10] / 100.0, starts[nb - 1] / 100.0);
