@@ -461,8 +461,9 @@ int32_t kg_solve(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, 
  * buffers, and the call makes no hipMalloc / hipFree / event creation.  A batch whose tables need more than the array
  * returns KG_ENOMEM with the size in kg_last_error (C2's 10 000 pods need about 20 MiB); a batch that names a resource or
  * label key the context has never seen returns KG_EUNSUPPORTED (the resident catalog tables would have to be rebuilt: run
- * kg_solve once).  Every call on one GPU uses the same array: calls that overlap on one GPU (two contexts, two threads)
- * race -- serialise them. */
+ * kg_solve once).  Every call on one GPU uses the same array, which keeps the last call's contents: the library holds a
+ * per-GPU mutex from carving the tables until the results are decoded, so calls that overlap on one GPU (two contexts, two
+ * threads) run one after the other instead of racing; their timing events are a pair set aside at kg_init. */
 int32_t kg_solve_noalloc(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_catalogs, kg_cluster* cluster /* may be NULL */,
                          const kg_pods_desc* pods, const kg_nodepools_desc* nodepools, kg_results* out);
 

@@ -111,8 +111,18 @@ int64_t parse_quantity_milli(std::string_view s) {
     if (e > 24) throw Unsupported("quantity exponent out of range");
     if (eneg) den = pow10(e); else num = 1000 * pow10(e);
   } else throw Unsupported("quantity suffix not handled by the native catalog build");
-  den *= pow10(frac > 30 ? 31 : frac);
   if (frac > 30) throw Unsupported("quantity finer than one milli-unit");
+  constexpr i128 I128_MAX = (i128)(~(unsigned __int128)0 >> 1);
+  {
+    // (every product is checked before it is formed: mant < 2^100, num <= 10^27, den <= 10^24 * 10^30 would overflow 128 bits)
+    const i128 f = pow10(frac);
+    if (den > I128_MAX / f) {  // the divisor alone exceeds anything mant * num can reach here (num is 1000 when den > 1)
+      if (mant == 0) return 0;
+      throw Unsupported("quantity finer than one milli-unit");
+    }
+    den *= f;
+  }
+  if (mant != 0 && num > I128_MAX / mant) throw Unsupported("quantity beyond int64 milli-units");
   const i128 scaled = mant * num;
   if (scaled % den != 0) throw Unsupported("quantity finer than one milli-unit");
   const i128 v = scaled / den;

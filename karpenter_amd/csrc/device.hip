@@ -87,7 +87,12 @@ __global__ void __launch_bounds__(64) k_solve_wave(DevProblem Pin, const SimStat
   static_assert(sizeof(SharedBase) + sizeof(uint64_t) * KG_POOL_WORDS <= 160 * 1024, "LDS of one CU");
   const DevProblem& P = Pin;
   const SimState S = sims[blockIdx.x];
-  solve_wave<DBG>(P, S, sh, pool, nqueue[blockIdx.x]);
+  // the same two descriptors in memory, for the rare paths (solve_wave.hpp: rare_view): Pin is the first kernel argument, so
+  // the kernel-argument segment starts with it; the state descriptors are written by the host before the launch and never
+  // by a kernel
+  const KG_CONST DevProblem* Pk = (const KG_CONST DevProblem*)__builtin_amdgcn_kernarg_segment_ptr();
+  const KG_CONST SimState* Sk = (const KG_CONST SimState*)(sims + blockIdx.x);
+  solve_wave<DBG>(P, S, Pk, Sk, sh, pool, nqueue[blockIdx.x]);
 }
 
 // k_sim_init: one workgroup per simulation copies the pristine state image into its slot and applies the patches
@@ -128,6 +133,10 @@ constexpr int KG_MAX_DEVICES = 64;
 static std::mutex g_dev_mu;
 static void* g_scratch_ptr[KG_MAX_DEVICES];             // per device: address of ITS copy of `scratch`
 static std::vector<hipEvent_t> g_events[KG_MAX_DEVICES];  // per device: timing events, created at init and reused
+static hipEvent_t g_noalloc_events[KG_MAX_DEVICES][2];   // per device: the pair kg_solve_noalloc's launch groups use (under g_scratch_mu)
+static std::mutex g_scratch_mu[KG_MAX_DEVICES];          // per device: one user of the scratch array at a time
+constexpr int KG_EVENT_POOL = 32;                         // events per device: 4 per consolidation round / 2 per launch group in flight
+static thread_local bool t_noalloc = false;
 // The stream of the context whose entry point the calling thread is in (set with the device by CtxLock): every copy, fill,
 // launch and event of the call goes to it, so calls on different contexts overlap on the GPU and none touches the null stream.
 static thread_local hipStream_t t_stream = nullptr;
@@ -151,11 +160,11 @@ std::string init(int device, int* device_out) {
     e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));  // (with `dev` current: each GPU has its own copy at its own address)
     if (e != hipSuccess || !p) return std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
     g_scratch_ptr[dev] = p;
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < KG_EVENT_POOL + 2; ++i) {
       hipEvent_t ev;
       e = hipEventCreate(&ev);
       if (e != hipSuccess) return std::string("hipEventCreate: ") + hipGetErrorString(e);
-      g_events[dev].push_back(ev);
+      if (i < 2) g_noalloc_events[dev][i] = ev; else g_events[dev].push_back(ev);
     }
   }
   return "";
@@ -182,6 +191,13 @@ void* scratch_ptr(size_t* bytes) {
   *bytes = KG_SCRATCH_BYTES;
   return g_scratch_ptr[dev];
 }
+std::mutex& scratch_mutex() {
+  int dev = 0;
+  ck(hipGetDevice(&dev), "hipGetDevice");
+  if (dev < 0 || dev >= KG_MAX_DEVICES) throw std::runtime_error("device index out of range");
+  return g_scratch_mu[dev];
+}
+void set_noalloc(bool on) { t_noalloc = on; }
 void* dmalloc(size_t bytes) {
   void* p = nullptr;
   ck(hipMalloc(&p, bytes ? bytes : 8), "hipMalloc");
@@ -219,32 +235,51 @@ void range_pop() { roctxRangePop(); }
 
 // HIP-event bracket of one launch group; the events come from the device's pool (created at kg_init) and go back to it.
 // Doubles as the group's roctx range.
-struct Timer {
-  hipEvent_t a, b;
-  int dev = 0;
-  static hipEvent_t take(int dev) {
-    {
-      std::lock_guard<std::mutex> lk(g_dev_mu);
-      if (!g_events[dev].empty()) { hipEvent_t e = g_events[dev].back(); g_events[dev].pop_back(); return e; }
-    }
-    hipEvent_t e;  // (more launches in flight than pooled events: concurrent callers)
-    ck(hipEventCreate(&e), "event");
-    return e;
-  }
-  explicit Timer(const char* name) {
+// N events of the current device for one launch group + its roctx range; both go back when the scope ends, also when a
+// launch or a wait throws in between.
+template <int N>
+struct EventScope {
+  hipEvent_t ev[N];
+  int dev = 0, taken = 0;
+  bool reserved = false;
+  explicit EventScope(const char* name) {
     roctxRangePushA(name);
-    ck(hipGetDevice(&dev), "hipGetDevice");
-    a = take(dev); b = take(dev);
-    ck(hipEventRecord(a, t_stream), "record");
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= KG_MAX_DEVICES) { roctxRangePop(); throw std::runtime_error("hipGetDevice"); }
+    if (t_noalloc && N <= 2) {  // kg_solve_noalloc: the pair set aside at kg_init (its caller holds the device's scratch mutex)
+      for (int i = 0; i < N; ++i) ev[i] = g_noalloc_events[dev][i];
+      reserved = true; taken = N;
+      return;
+    }
+    std::unique_lock<std::mutex> lk(g_dev_mu);
+    while (taken < N) {
+      if (!g_events[dev].empty()) { ev[taken++] = g_events[dev].back(); g_events[dev].pop_back(); continue; }
+      lk.unlock();  // (more launch groups in flight on this device than pooled events: many concurrent contexts)
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) { release(); throw std::runtime_error("hipEventCreate"); }
+      ev[taken++] = e;
+      lk.lock();
+    }
   }
-  float stop() {
-    ck(hipEventRecord(b, t_stream), "record");
-    ck(hipEventSynchronize(b), "kernel execution");
-    float ms = 0;
-    ck(hipEventElapsedTime(&ms, a, b), "elapsed");
+  void release() {
+    if (!reserved) {
+      std::lock_guard<std::mutex> lk(g_dev_mu);
+      for (int i = 0; i < taken; ++i) g_events[dev].push_back(ev[i]);
+    }
+    taken = 0;
     roctxRangePop();
-    std::lock_guard<std::mutex> lk(g_dev_mu);
-    g_events[dev].push_back(a); g_events[dev].push_back(b);
+  }
+  ~EventScope() { release(); }
+  EventScope(const EventScope&) = delete;
+  EventScope& operator=(const EventScope&) = delete;
+};
+struct Timer {
+  EventScope<2> es;
+  explicit Timer(const char* name) : es(name) { ck(hipEventRecord(es.ev[0], t_stream), "record"); }
+  float stop() {
+    ck(hipEventRecord(es.ev[1], t_stream), "record");
+    ck(hipEventSynchronize(es.ev[1]), "kernel execution");
+    float ms = 0;
+    ck(hipEventElapsedTime(&ms, es.ev[0], es.ev[1]), "elapsed");
     return ms;
   }
 };
@@ -312,11 +347,8 @@ void launch_sim_gather(const DevProblem& P, const SimBatch& B, const SimState* s
 void launch_sim_round(const DevProblem& P, const SimBatch& B, const SimState* sims, int block, float ms[3]) {
   ms[0] = ms[1] = ms[2] = 0;
   if (!B.nsims) return;
-  roctxRangePushA("kg consolidation round (k_sim_init, k_simulate, k_sim_gather)");
-  int dev = 0;
-  ck(hipGetDevice(&dev), "hipGetDevice");
-  hipEvent_t ev[4];
-  for (int i = 0; i < 4; ++i) ev[i] = Timer::take(dev);
+  EventScope<4> es("kg consolidation round (k_sim_init, k_simulate, k_sim_gather)");
+  hipEvent_t* ev = es.ev;
   ck(hipEventRecord(ev[0], t_stream), "record");
   hipLaunchKernelGGL(k_sim_init, dim3(B.nsims), dim3(256), 0, t_stream, P, B);
   ck(hipEventRecord(ev[1], t_stream), "record");
@@ -329,9 +361,6 @@ void launch_sim_round(const DevProblem& P, const SimBatch& B, const SimState* si
   ck(hipGetLastError(), "consolidation round launch");
   ck(hipEventSynchronize(ev[3]), "kernel execution");
   for (int i = 0; i < 3; ++i) ck(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]), "elapsed");
-  roctxRangePop();
-  std::lock_guard<std::mutex> lk(g_dev_mu);
-  for (int i = 0; i < 4; ++i) g_events[dev].push_back(ev[i]);
 }
 const char* backend() { return "hip-gfx950"; }
 

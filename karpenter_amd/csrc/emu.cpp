@@ -19,6 +19,8 @@ void* scratch_ptr(size_t* bytes) {
   *bytes = 32u << 20;
   return p;
 }
+std::mutex& scratch_mutex() { static std::mutex m; return m; }
+void set_noalloc(bool) {}
 void* dmalloc(size_t bytes) { return std::calloc(bytes ? bytes : 8, 1); }
 void dfree(void* p) { std::free(p); }
 void* host_pinned(size_t bytes) { return std::malloc(bytes ? bytes : 8); }

@@ -2,6 +2,7 @@
 // product) and by emu.cpp (host loops, TEST-ONLY emulation build).
 #pragma once
 #include <cstddef>
+#include <mutex>
 #include <string>
 
 #include "solve_core.hpp"
@@ -19,6 +20,12 @@ void* stream_create();  // on the current device; never the null stream
 void stream_destroy(void* stream);
 // the current device's copy of the static scratch array and its size (device.hip: `scratch`)
 void* scratch_ptr(size_t* bytes);
+// ... and the mutex that serialises its users: every context on a GPU shares that GPU's array, so kg_solve_noalloc holds
+// this from carving its tables until its results are decoded (contexts on other GPUs are not affected)
+std::mutex& scratch_mutex();
+// the calling thread is inside kg_solve_noalloc: its launch groups take the timing events reserved for that entry point at
+// kg_init (never hipEventCreate, whatever other contexts have taken from the device's pool)
+void set_noalloc(bool on);
 void* dmalloc(size_t bytes);
 void* host_pinned(size_t bytes);  // page-locked host memory: a D2H into it is one DMA, no staging copy
 void host_pinned_free(void* p);

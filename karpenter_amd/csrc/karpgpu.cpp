@@ -1857,6 +1857,11 @@ int32_t kg_solve_noalloc(kg_ctx* ctx, kg_catalog* const* catalogs, uint32_t n_ca
   KG_GUARD_BEGIN
   if (n_catalogs != 1) throw Unsupported("kg_solve_noalloc: one catalog per solve (a merged view of several has to be built: an allocation)");
   kg_catalog* view = effective_catalog(ctx, catalogs, n_catalogs, nodepools);
+  // every context on this GPU shares the GPU's one array: one user at a time, from carving the tables until the results
+  // have been decoded (two contexts of one device, each under its own context lock, would otherwise overwrite each
+  // other's problem image and state mid-kernel)
+  std::lock_guard<std::mutex> scratch_guard(hal::scratch_mutex());
+  struct NoAllocScope { NoAllocScope() { hal::set_noalloc(true); } ~NoAllocScope() { hal::set_noalloc(false); } } noalloc_scope;
   FixedArena fa;
   fa.base = (uint8_t*)hal::scratch_ptr(&fa.cap);
   return solve_impl(ctx, &view, cluster, pods, nodepools, out, true, &fa);

@@ -21,6 +21,34 @@ namespace kg {
 // spilled to a VGPR lane and reloaded with v_readlane; values that only feed vector instructions cost nothing as VGPRs.
 #define KG_VREG64(x) asm volatile("" : "+v"(x))
 
+// The descriptors of a launch (DevProblem in the kernel-argument segment, the SimState of this Solve in the state image) hold
+// about 130 pointers and sizes; a placement that lands on an in-flight NodeClaim needs about twenty of them.  Read through
+// the by-value copies, every field is loaded at the kernel's entry and occupies scalar registers for the whole Solve (the
+// compiler then parks them in VGPR lanes and pays a v_readlane per use).  The paths that run once per Solve or once per
+// NodeClaim (table staging, a new NodeClaim, a false survivor, Preferences.Relax, the final columns) therefore read their
+// fields through a pointer in the CONSTANT address space that is made opaque where the path begins: the scalar loads stay on
+// that path, and only the two base pointers live across the placement loop.
+#define KG_CONST __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ const T& rare_view(const KG_CONST T* p) {
+  asm volatile("" : "+s"(p));
+  return *(const T*)p;
+}
+
+// has_mask1 (solve_core.hpp) with the bound masks read through the rare view
+__device__ __forceinline__ uint64_t has_mask1_rare(const KG_CONST DevProblem* Pk, int a, SReq r) {
+  if (!(r.meta & RM_PRESENT)) return ~0ull;
+  if (!(r.meta & RM_COMPL)) return r.word;
+  uint64_t m = ~r.word;
+  const uint32_t gt = rm_gt(r.meta), lt = rm_lt(r.meta);
+  if (__builtin_expect((gt | lt) != 0, 0)) {
+    const DevProblem& Pb = rare_view(Pk);
+    if (gt) m &= Pb.gtmask[Pb.bndmask_off[a] + (gt - 1)];
+    if (lt) m &= Pb.ltmask[Pb.bndmask_off[a] + (lt - 1)];
+  }
+  return m;
+}
+
 // Step 3-6 of NodeClaim.Add with the claim row in registers: lane a holds meta[a], lane i bits[i], lanes 8r the requests of
 // resource r, lane w word w of the option mask.  FRESH: the row is a NodeClaim just made from a template (every entry
 // counts as changed, template entries and the valid-type mask join the filter, hasOffering is always evaluated).
@@ -30,9 +58,11 @@ struct LaneTabs {
   uint32_t spa, spoff;       // lane i < nspec: active slot of 1-word key i and its word offset in a claim row
   uint32_t tn, tbase, toff;  // lanes [8r, 8r + 8): number of fit thresholds of resource r, their base in sh.thr_val, in the catalog
 };
+// P: the problem as the caller reads it (FRESH: its rare view); Pk: the same struct for the branches that are rare even on
+// the hot path (Gt / Lt bounds, entries whose value words did not fit the pod context, negative operators, zone ids).
 template <bool FRESH>
-__device__ __forceinline__ bool wave_add(const DevProblem& P, const SharedBase& sh, const uint64_t* thr_rows, const LaneTabs& lt, const PodCtx& pc, uint32_t lane, uint32_t need,
-                                         uint32_t tmpl, uint32_t& meta, uint64_t& bits, int64_t& req, uint64_t& m, bool* compat) {
+__device__ __forceinline__ bool wave_add(const DevProblem& P, const KG_CONST DevProblem* Pk, const SharedBase& sh, const uint64_t* thr_rows, const LaneTabs& lt, const PodCtx& pc,
+                                         uint32_t lane, uint32_t need, uint32_t tmpl, uint32_t& meta, uint64_t& bits, int64_t& req, uint64_t& m, bool* compat) {
   const uint32_t NR = (uint32_t)P.R, TW = (uint32_t)P.TW;
   const uint32_t rg = lane >> 3;
   uint4 pe4;
@@ -54,7 +84,7 @@ __device__ __forceinline__ bool wave_add(const DevProblem& P, const SharedBase& 
     const bool inr = lane >= aoff && lane < aoff + w;
     uint64_t y = 0;
     if (pbits != 0xFFFF) { if (inr) { y = pc.vc.ebits[pbits + lane - aoff]; KG_OPAQUE64(y); } }
-    else if (inr) y = P.rs_bits[P.e_bits[rl32(pe4.x, j)] + lane - aoff];
+    else { const DevProblem& Pb = rare_view(Pk); if (inr) y = Pb.rs_bits[Pb.e_bits[rl32(pe4.x, j)] + lane - aoff]; }
     if (!(cma & RM_PRESENT)) {
       if (!((P.well_known_slots >> a) & 1) && !op_neg((int)opc)) { ok = false; break; }
       if (op_neg((int)opc)) ent_dne_ok |= 1u << j;
@@ -67,15 +97,20 @@ __device__ __forceinline__ bool wave_add(const DevProblem& P, const SharedBase& 
     const bool xc = cma & RM_COMPL, yc = pm & RM_COMPL;
     const uint32_t gt = rm_gt(cma) > rm_gt(pm) ? rm_gt(cma) : rm_gt(pm);
     const uint32_t lt = min_nz(rm_lt(cma), rm_lt(pm));
-    const bool dne = gt && lt && P.gtval[P.bnd_off[a] + gt - 1] >= P.ltval[P.bnd_off[a] + lt - 1];
-    const uint32_t mm = (xc && yc && !dne) ? rm_make(true, gt, lt) : rm_make(false, 0, 0);
+    bool dne = false;
     const uint64_t x = bits;
     uint64_t r = x;
-    if (inr) {
-      r = dne ? 0 : ((xc && yc) ? (x | y) : (xc ? (y & ~x) : (yc ? (x & ~y) : (x & y))));
-      if (!dne && gt) r &= P.gtmask[P.bndmask_off[a] + (size_t)(gt - 1) * w + (lane - aoff)];
-      if (!dne && lt) r &= P.ltmask[P.bndmask_off[a] + (size_t)(lt - 1) * w + (lane - aoff)];
+    if (inr) r = (xc && yc) ? (x | y) : (xc ? (y & ~x) : (yc ? (x & ~y) : (x & y)));
+    if (__builtin_expect((gt | lt) != 0, 0)) {  // Gt / Lt bounds on the key
+      const DevProblem& Pb = rare_view(Pk);
+      dne = gt && lt && Pb.gtval[Pb.bnd_off[a] + gt - 1] >= Pb.ltval[Pb.bnd_off[a] + lt - 1];
+      if (inr) {
+        if (dne) r = 0;
+        if (!dne && gt) r &= Pb.gtmask[Pb.bndmask_off[a] + (size_t)(gt - 1) * w + (lane - aoff)];
+        if (!dne && lt) r &= Pb.ltmask[Pb.bndmask_off[a] + (size_t)(lt - 1) * w + (lane - aoff)];
+      }
     }
+    const uint32_t mm = (xc && yc && !dne) ? rm_make(true, gt, lt) : rm_make(false, 0, 0);
     const bool anyb = __ballot(inr && r != 0) != 0, canyb = __ballot(inr && x != 0) != 0;
     const bool chg = mm != cma || __ballot(inr && r != x) != 0;
     if (inr) bits = r;
@@ -118,8 +153,9 @@ __device__ __forceinline__ bool wave_add(const DevProblem& P, const SharedBase& 
 #pragma unroll
     for (int r = 0; r < KG_MAXR; ++r) { tmk[r] = thr_rows[rl32(lrow, 8 * r) * TW + w]; KG_OPAQUE64(tmk[r]); }  // (row 0 for unused lanes)
   } else {
+    const DevProblem& Pt = rare_view(Pk);  // (the fit-threshold rows did not fit the LDS pool)
 #pragma unroll
-    for (int r = 0; r < KG_MAXR; ++r) tmk[r] = P.thr_mask[(size_t)rl32(trow, 8 * r) * TW + w];  // (unconditional: one round trip)
+    for (int r = 0; r < KG_MAXR; ++r) tmk[r] = Pt.thr_mask[(size_t)rl32(trow, 8 * r) * TW + w];  // (unconditional: one round trip)
   }
 #pragma unroll
   for (int r = 0; r < KG_MAXR; ++r) tmk[r] = ((useb >> (8 * r)) & 1) ? tmk[r] : ~0ull;
@@ -127,7 +163,7 @@ __device__ __forceinline__ bool wave_add(const DevProblem& P, const SharedBase& 
     const uint32_t j = (uint32_t)__builtin_ctz(em);
     uint64_t f = pc.eam[j][w];
     KG_OPAQUE64(f);
-    if ((ent_dne_ok >> j) & 1) f |= P.kU[(size_t)(rl32(pe4.w, j) & 0xFF) * TW + w];
+    if ((ent_dne_ok >> j) & 1) { const DevProblem& Pb = rare_view(Pk); f |= Pb.kU[(size_t)(rl32(pe4.w, j) & 0xFF) * TW + w]; }
     m &= f;
   }
   if (FRESH) {
@@ -162,10 +198,10 @@ __device__ __forceinline__ bool wave_add(const DevProblem& P, const SharedBase& 
       const bool present = sp.meta & RM_PRESENT;
       sp.word = present ? rl64(bits, rl32(spoff, (uint32_t)i)) : 0;
       const bool changed = ((sp_changed >> i) & 1) || (FRESH && present);
-      const uint64_t hm = has_mask1(P, (int)a, sp);
+      const uint64_t hm = has_mask1_rare(Pk, (int)a, sp);
       if (changed && present) {
         uint64_t f = P.kN[(size_t)a * TW + w];
-        if (op_neg(opclass(sp.meta & RM_COMPL, sp.word != 0))) f |= P.kU[(size_t)a * TW + w];
+        if (op_neg(opclass(sp.meta & RM_COMPL, sp.word != 0))) { const DevProblem& Pb = rare_view(Pk); f |= Pb.kU[(size_t)a * TW + w]; }
         for (uint64_t q = hm & ((1ull << KG_SPV) - 1); q; q &= q - 1) { uint64_t g = sh.stw[i][ctz64(q)][w]; KG_OPAQUE64(g); f |= g; }
         m &= f;
       }
@@ -174,8 +210,9 @@ __device__ __forceinline__ bool wave_add(const DevProblem& P, const SharedBase& 
       if (i == P.slot_ct) ctmask = hm;
       if (i == P.slot_zid) {
         uint64_t zm = 0;
+        const DevProblem& Pb = rare_view(Pk);
         for (int z = 0; z < P.n_zone_vals; ++z) {
-          const uint8_t zid = P.zone_zid[z];
+          const uint8_t zid = Pb.zone_zid[z];
           if (zid == 0xFF || ((hm >> zid) & 1)) zm |= 1ull << z;
         }
         zmask &= zm;
@@ -257,15 +294,16 @@ constexpr uint32_t KG_POOL_WORDS = (160 * 1024 - (uint32_t)sizeof(SharedBase)) /
 constexpr uint32_t KG_WORD = 2 * KG_ORD;
 // (lds: every position in use is below KG_WORD -- a uniform fact the callers pass down, so that the common case has no
 // per-lane branch and no global load to wait for)
-__device__ __forceinline__ unsigned long long word_get(const SimState& S, const SharedBase& sh, bool lds, uint32_t p) {
+// (S: the state descriptor behind its rare view -- the global half of the order is only touched beyond 2 048 NodeClaims)
+__device__ __forceinline__ unsigned long long word_get(const KG_CONST SimState* S, const SharedBase& sh, bool lds, uint32_t p) {
   if (lds || p < KG_WORD) { unsigned long long v = (&sh.ord[0][0])[lds ? (p & (KG_WORD - 1)) : p]; KG_OPAQUE64(v); return v; }
-  return S.ordg[p];
+  return rare_view(S).ordg[p];
 }
-__device__ __forceinline__ void word_set(const SimState& S, SharedBase& sh, bool lds, uint32_t p, unsigned long long v) {
-  if (lds || p < KG_WORD) (&sh.ord[0][0])[lds ? (p & (KG_WORD - 1)) : p] = v; else S.ordg[p] = v;
+__device__ __forceinline__ void word_set(const KG_CONST SimState* S, SharedBase& sh, bool lds, uint32_t p, unsigned long long v) {
+  if (lds || p < KG_WORD) (&sh.ord[0][0])[lds ? (p & (KG_WORD - 1)) : p] = v; else rare_view(S).ordg[p] = v;
 }
 // end of the k-pod group: first position whose claim holds more than k pods (64-ary search)
-__device__ __forceinline__ uint32_t word_group_end(const SimState& S, const SharedBase& sh, bool lds, uint32_t nclaims, uint32_t k, uint32_t lane) {
+__device__ __forceinline__ uint32_t word_group_end(const KG_CONST SimState* S, const SharedBase& sh, bool lds, uint32_t nclaims, uint32_t k, uint32_t lane) {
   uint32_t stride = 1;
   while ((unsigned long long)stride * 64 < nclaims) stride *= 64;
   uint32_t lo = 0;
@@ -300,8 +338,11 @@ __device__ __forceinline__ void ctx_fetch_image(const DevProblem& P, PodCtx& nx,
 // The whole Solve.  Preconditions (checked by the host before it picks this kernel): no topology groups, no existing
 // nodes, no minValues, TW <= KG_TWLDS, every table stages into LDS, visit counters off.
 // DBG: with the per-section cycle accounting (its counters would otherwise cost the production kernel two dozen scalar registers)
+// P, S: the by-value copies (the placement loop's fields live in scalar registers); Pk, Sk: the same structs in memory for
+// the rare paths (rare_view above).
 template <bool DBG>
-__device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& S, SharedBase& sh, uint64_t* pool, uint32_t n_queue) {
+__device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& S, const KG_CONST DevProblem* Pk, const KG_CONST SimState* Sk, SharedBase& sh, uint64_t* pool,
+                                           uint32_t n_queue) {
   const uint32_t lane = threadIdx.x & 63;
   // cycle accounting per section of a placement (stats & 8; debug): registers, written once at the end
   constexpr bool WT = DBG;
@@ -312,9 +353,8 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
   // ... and inside "new NodeClaim" (also counted there): limits + template row, NodeClaim.Add, row stores, headroom / limits, order
   unsigned long long wn_last = 0, wn[5] = {0, 0, 0, 0, 0};
 #define KG_WN(k) do { if (WT) { const unsigned long long n_ = clock64(); if ((k) >= 0) wn[(k) < 0 ? 0 : (k)] += n_ - wn_last; wn_last = n_; } } while (0)
-  stage_tables<64>(P, sh);
-  const uint32_t Ka = (uint32_t)P.Ka, Wa = (uint32_t)P.Wa, NR = (uint32_t)P.R, TW = (uint32_t)P.TW, NP = (uint32_t)P.NP;
-  const size_t Cmax = (size_t)P.Cmax;
+  stage_tables<64>(rare_view(Pk), sh);
+  const uint32_t NR = (uint32_t)P.R, TW = (uint32_t)P.TW;
   const uint32_t rg = lane >> 3;
   // one LDS pool: the fit-threshold rows of the active resources (in the order of sh.thr_val) when they take at most
   // half of it, then the prefilter records of as many NodeClaims as fit behind them
@@ -325,9 +365,10 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
     for (uint32_t r = 0; r < NR; ++r) tot += sh.a_thr_n[r];
     tot = KG_UNI(tot);
     if (tot * TW <= KG_POOL_WORDS / 2) {
+      const uint64_t* thr_mask = rare_view(Pk).thr_mask;
       for (uint32_t r = 0; r < NR; ++r) {
         const uint32_t n = KG_UNI(sh.a_thr_n[r]), b = KG_UNI(sh.thr_base[r]), o = KG_UNI(sh.a_thr_off[r]);
-        for (uint32_t i = lane; i < n * TW; i += 64) pool[b * TW + i] = P.thr_mask[(size_t)o * TW + i];
+        for (uint32_t i = lane; i < n * TW; i += 64) pool[b * TW + i] = thr_mask[(size_t)o * TW + i];
       }
       thr_rows = pool;
       pf_off = (tot * TW + 1) & ~1u;
@@ -433,7 +474,7 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         if (P.has_ports) bad |= (uint32_t)((S.c_ports[c] & hp_conf) != 0);
         ok = hcok && bad == 0;
       } else if (pos < nclaims) {
-        oe = word_get(S, sh, lds, pos);
+        oe = word_get(Sk, sh, lds, pos);
         const uint32_t c = (uint32_t)oe;
         // the claim's prefilter record: twelve 16-byte loads from consecutive addresses, one round trip
         const KG_GLOBAL uint4* rec = (const KG_GLOBAL uint4*)(S.c_row + (size_t)c * KG_ROW_WORDS);
@@ -474,21 +515,22 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         int64_t phd = 0;  // lanes 0..3: the headroom of resources 0..3
         if (lane < 4) phd = (int64_t)row[lane];
         const uint64_t w6_v = row[6], w7_v = row[7];
-        const uint32_t endk = word_group_end(S, sh, lds, nclaims, wnp, lane);  // (LDS work under the row's round trip)
+        const uint32_t endk = word_group_end(Sk, sh, lds, nclaims, wnp, lane);  // (LDS work under the row's round trip)
         const uint64_t w6 = KG_UNI64(w6_v), w7 = KG_UNI64(w7_v);
         const uint32_t tm = (uint32_t)w6, stamp = (uint32_t)w7, hst = (uint32_t)(w7 >> 32);
         const int64_t req0 = req;
         uint64_t m = cm;
         bool compat = true;
         KG_W(2);
-        const bool feasible = wave_add<false>(P, sh, thr_rows, lt, pc, lane, need, tm, meta, bits, req, m, &compat);
+        const bool feasible = wave_add<false>(P, Pk, sh, thr_rows, lt, pc, lane, need, tm, meta, bits, req, m, &compat);
         KG_W(3);
         if (WT) wt[10] += 1;
         if (__builtin_expect(!feasible, 0)) {
           if (hst != stamp) {
             // the prefilter let an infeasible claim through: recompute its headroom (its options changed since)
+            const DevProblem& Pr = rare_view(Pk);
             for (uint32_t r = 0; r < NR && r < 4; ++r) {
-              const int64_t mx = wave_max_over_mask(P.alloc + (size_t)KG_UNI(sh.a_res[r]) * P.T, cm, TW, (uint32_t)P.T, lane);
+              const int64_t mx = wave_max_over_mask(Pr.alloc + (size_t)KG_UNI(sh.a_res[r]) * Pr.T, cm, TW, (uint32_t)Pr.T, lane);
               const int64_t rq = (int64_t)rl64((uint64_t)req0, 8 * r);
               if (lane == 0) { row[r] = (uint64_t)(mx - rq); if (c < pfn) pf[(size_t)c * pfw + r] = (uint64_t)(mx - rq); }
             }
@@ -526,10 +568,10 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         for (uint32_t p0 = wpos; p0 + 1 < endk; p0 += 64) {
           const uint32_t p = p0 + lane;
           unsigned long long v = 0;
-          if (p + 1 < endk) v = word_get(S, sh, lds, p + 1);
-          if (p + 1 < endk) word_set(S, sh, lds, p, v);
+          if (p + 1 < endk) v = word_get(Sk, sh, lds, p + 1);
+          if (p + 1 < endk) word_set(Sk, sh, lds, p, v);
         }
-        if (lane == 0) word_set(S, sh, lds, endk - 1, ((unsigned long long)(wnp + 1) << 32) | c);
+        if (lane == 0) word_set(Sk, sh, lds, endk - 1, ((unsigned long long)(wnp + 1) << 32) | c);
         last_c = c; last_new = 0; last_npods = wnp; last_stamp = stamp;
         seq += 1;
         placed = true;
@@ -538,7 +580,10 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
     }
     if (!placed) KG_W(1);
     // ---- a new NodeClaim from each template in weight order
-    if (__builtin_expect(!placed && nclaims < (uint32_t)P.Cmax, 0)) {
+    if (__builtin_expect(!placed, 0)) {
+      const DevProblem& Pr = rare_view(Pk);
+      const SimState& Sr = rare_view(Sk);
+      const uint32_t NP = nclaims < (uint32_t)Pr.Cmax ? (uint32_t)Pr.NP : 0u;  // (no room for another NodeClaim: no template is tried)
       const uint32_t c = nclaims;
       for (uint32_t t = 0; t < NP && !placed; ++t) {
         KG_WN(-1);
@@ -546,12 +591,12 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         uint64_t cm = 0;
         if (lane < TW) {
           cm = ~0ull;
-          if (lane == TW - 1 && (P.T & 63)) cm = (1ull << (P.T & 63)) - 1;
-          if (P.tmpl_has_limits[t]) {
+          if (lane == TW - 1 && (Pr.T & 63)) cm = (1ull << (Pr.T & 63)) - 1;
+          if (Pr.tmpl_has_limits[t]) {
             for (uint32_t r = 0; r < NR; ++r) {
-              if (!P.tmpl_limit_res[(size_t)r * NP + t]) continue;
-              const int idx = thr_lookup_le(P.cthr_val + sh.a_cthr_off[r], (int)sh.a_cthr_n[r], S.remaining[(size_t)r * NP + t]);
-              if (idx < 0) cm = 0; else cm &= P.cthr_mask[((size_t)sh.a_cthr_off[r] + idx) * TW + lane];
+              if (!Pr.tmpl_limit_res[(size_t)r * NP + t]) continue;
+              const int idx = thr_lookup_le(Pr.cthr_val + sh.a_cthr_off[r], (int)sh.a_cthr_n[r], Sr.remaining[(size_t)r * NP + t]);
+              if (idx < 0) cm = 0; else cm &= Pr.cthr_mask[((size_t)sh.a_cthr_off[r] + idx) * TW + lane];
             }
           }
         }
@@ -561,22 +606,22 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         // NewNodeClaim: the template's requirements and daemon overhead
         uint32_t meta = 0;
         uint64_t bits = 0;
-        const uint32_t trs = P.tmpl_rs[t];
-        for (uint32_t e = P.rs_off[trs]; e < P.rs_off[trs + 1]; ++e) {
-          const uint32_t a = P.e_slot[e], off = sh.aoff[a], w = sh.aw[a];
-          if (lane == a) meta = P.e_meta[e];
-          if (lane >= off && lane < off + w) bits = P.rs_bits[P.e_bits[e] + lane - off];
+        const uint32_t trs = Pr.tmpl_rs[t];
+        for (uint32_t e = Pr.rs_off[trs]; e < Pr.rs_off[trs + 1]; ++e) {
+          const uint32_t a = Pr.e_slot[e], off = sh.aoff[a], w = sh.aw[a];
+          if (lane == a) meta = Pr.e_meta[e];
+          if (lane >= off && lane < off + w) bits = Pr.rs_bits[Pr.e_bits[e] + lane - off];
         }
         int64_t req = 0;
-        if (rg < NR) req = P.tmpl_req[(size_t)rg * NP + t];
+        if (rg < NR) req = Pr.tmpl_req[(size_t)rg * NP + t];
         uint64_t m = cm;
         bool compat = true;
         KG_WN(0);
-        const bool feasible = wave_add<true>(P, sh, thr_rows, lt, pc, lane, need, t, meta, bits, req, m, &compat);
+        const bool feasible = wave_add<true>(Pr, Pk, sh, thr_rows, lt, pc, lane, need, t, meta, bits, req, m, &compat);
         KG_WN(1);
         if (!feasible) { reason |= compat ? 8u : 2u; continue; }
         // ---- commit the new claim: appended to the end of the one-pod group
-        KG_GLOBAL uint64_t* row = S.c_row + (size_t)c * KG_ROW_WORDS;
+        KG_GLOBAL uint64_t* row = Sr.c_row + (size_t)c * KG_ROW_WORDS;
         if (lane < KG_MAXKA) ((KG_GLOBAL uint32_t*)(row + KG_ROW_META))[lane] = meta;
         row[KG_ROW_BITS + lane] = bits;
         if ((lane & 7) == 0) row[KG_ROW_REQ + rg] = (uint64_t)req;
@@ -598,32 +643,32 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
         }
         KG_WN(2);
         for (uint32_t r = 0; r < NR; ++r) {
-          const int64_t mx = wave_max_over_mask(P.alloc + (size_t)KG_UNI(sh.a_res[r]) * P.T, m, TW, (uint32_t)P.T, lane);
+          const int64_t mx = wave_max_over_mask(Pr.alloc + (size_t)KG_UNI(sh.a_res[r]) * Pr.T, m, TW, (uint32_t)Pr.T, lane);
           const int64_t rq = (int64_t)rl64((uint64_t)req, 8 * r);
           if (lane == 0 && r < 4) { row[r] = (uint64_t)(mx - rq); if (c < pfn) pf[(size_t)c * pfw + r] = (uint64_t)(mx - rq); }
           // subtractMax: the worst-case capacity of the remaining options is charged against the limits
-          if (P.tmpl_has_limits[t] && P.tmpl_limit_res[(size_t)r * NP + t]) {
-            const int64_t cx = wave_max_over_mask(P.cap + (size_t)KG_UNI(sh.a_res[r]) * P.T, m, TW, (uint32_t)P.T, lane);
-            if (lane == 0) S.remaining[(size_t)r * NP + t] -= cx;
+          if (Pr.tmpl_has_limits[t] && Pr.tmpl_limit_res[(size_t)r * NP + t]) {
+            const int64_t cx = wave_max_over_mask(Pr.cap + (size_t)KG_UNI(sh.a_res[r]) * Pr.T, m, TW, (uint32_t)Pr.T, lane);
+            if (lane == 0) Sr.remaining[(size_t)r * NP + t] -= cx;
           }
         }
         if (lane == 0) {
-          S.pod_kind[pod_row(S, pod)] = 2;
-          S.pod_index[pod_row(S, pod)] = (int32_t)c;
-          if (P.has_ports) S.c_ports[c] = pc.vc.hp_use;
+          Sr.pod_kind[pod_row(Sr, pod)] = 2;
+          Sr.pod_index[pod_row(Sr, pod)] = (int32_t)c;
+          if (Pr.has_ports) Sr.c_ports[c] = pc.vc.hp_use;
         }
         KG_WN(3);
-        const uint32_t endk = word_group_end(S, sh, lds, nclaims, 1, lane);
+        const uint32_t endk = word_group_end(Sk, sh, lds, nclaims, 1, lane);
         // shift [endk, nclaims) right by one, from the top
         for (uint32_t hi = nclaims; hi > endk;) {
           const uint32_t lo2 = hi - endk > 64 ? hi - 64 : endk;
           const uint32_t p = lo2 + lane;
           unsigned long long v = 0;
-          if (p < hi) v = word_get(S, sh, lds, p);
-          if (p < hi) word_set(S, sh, lds, p + 1, v);
+          if (p < hi) v = word_get(Sk, sh, lds, p);
+          if (p < hi) word_set(Sk, sh, lds, p + 1, v);
           hi = lo2;
         }
-        if (lane == 0) word_set(S, sh, lds, endk, (1ull << 32) | c);
+        if (lane == 0) word_set(Sk, sh, lds, endk, (1ull << 32) | c);
         last_c = c; last_new = 1;
         nclaims += 1; seq += 1;
         placed = true;
@@ -634,16 +679,17 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
     if (__builtin_expect(!placed, 0)) {
       // ---- Preferences.Relax + Queue.Push (the push lands behind the entries already fetched: they were only fetched
       // when the queue held them)
+      const SimState& Sr = rare_view(Sk);
       const int32_t vnext = (int32_t)KG_UNI((uint32_t)pc.vc.v.next);
       if (lane == 0) {
-        S.pod_kind[pod_row(S, pod)] = 0;
-        S.pod_index[pod_row(S, pod)] = -1;
-        S.pod_reason[pod_row(S, pod)] = reason ? reason : 8;
+        Sr.pod_kind[pod_row(Sr, pod)] = 0;
+        Sr.pod_index[pod_row(Sr, pod)] = -1;
+        Sr.pod_reason[pod_row(Sr, pod)] = reason ? reason : 8;
         uint4 qn;
         qn.x = pod;
-        if (vnext >= 0) { qn.y = (uint32_t)vnext; qn.z = 0; qn.w = 0; S.header[1] += 1; }
+        if (vnext >= 0) { qn.y = (uint32_t)vnext; qn.z = 0; qn.w = 0; Sr.header[1] += 1; }
         else { qn.y = variant; qn.z = epoch; qn.w = qlen + 1; }
-        ((KG_GLOBAL uint4*)S.queue)[(qhead + qlen) % QCAP] = qn;
+        ((KG_GLOBAL uint4*)Sr.queue)[(qhead + qlen) % QCAP] = qn;
       }
       qlen += 1;
       if (vnext >= 0) epoch += 1;
@@ -667,28 +713,32 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
   }
   // ---- the columns the host decodes, from the rows
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  const DevProblem& Pe = rare_view(Pk);
+  const SimState& Se = rare_view(Sk);
+  const uint32_t Ka = (uint32_t)Pe.Ka, Wa = (uint32_t)Pe.Wa;
+  const size_t Cmax = (size_t)Pe.Cmax;
   for (uint32_t c = 0; c < nclaims; ++c) {
-    const KG_GLOBAL uint64_t* row = S.c_row + (size_t)c * KG_ROW_WORDS;
-    if (lane < Ka) S.c_meta[(size_t)lane * Cmax + c] = ((const KG_GLOBAL uint32_t*)(row + KG_ROW_META))[lane];
-    if (lane < Wa) S.c_bits[(size_t)lane * Cmax + c] = row[KG_ROW_BITS + lane];
-    if (lane < NR) S.c_req[(size_t)lane * Cmax + c] = (int64_t)row[KG_ROW_REQ + lane];
-    if (lane < TW) S.c_mask[(size_t)lane * Cmax + c] = row[KG_ROW_MASK + lane];
+    const KG_GLOBAL uint64_t* row = Se.c_row + (size_t)c * KG_ROW_WORDS;
+    if (lane < Ka) Se.c_meta[(size_t)lane * Cmax + c] = ((const KG_GLOBAL uint32_t*)(row + KG_ROW_META))[lane];
+    if (lane < Wa) Se.c_bits[(size_t)lane * Cmax + c] = row[KG_ROW_BITS + lane];
+    if (lane < NR) Se.c_req[(size_t)lane * Cmax + c] = (int64_t)row[KG_ROW_REQ + lane];
+    if (lane < TW) Se.c_mask[(size_t)lane * Cmax + c] = row[KG_ROW_MASK + lane];
     if (lane == 0) {
       const uint64_t w6 = row[6], w7 = row[7];
-      S.c_tmpl[c] = (uint16_t)(uint32_t)w6; S.c_npods[c] = (uint32_t)(w6 >> 32); S.c_stamp[c] = (uint32_t)w7;
+      Se.c_tmpl[c] = (uint16_t)(uint32_t)w6; Se.c_npods[c] = (uint32_t)(w6 >> 32); Se.c_stamp[c] = (uint32_t)w7;
     }
   }
   if (WT && lane == 0) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) S.counters[64 + i] = wt[i];
+    for (int i = 0; i < 12; ++i) Se.counters[64 + i] = wt[i];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) S.counters[80 + i] = wn[i];
+    for (int i = 0; i < 5; ++i) Se.counters[80 + i] = wn[i];
   }
 #undef KG_W
 #undef KG_WN
   if (lane == 0) {
-    S.header[0] = nclaims;
-    S.header[2] = last_c; S.header[3] = last_npods; S.header[4] = last_stamp; S.header[5] = last_new;
+    Se.header[0] = nclaims;
+    Se.header[2] = last_c; Se.header[3] = last_npods; Se.header[4] = last_stamp; Se.header[5] = last_new;
   }
 }
 

@@ -54,11 +54,15 @@ def check_ec2_build(L):
     for vi, ctx in enumerate(variants):
         types = _check_tables(L, infos, ctx, oz, doc if vi == 0 else None)
     # a quantity finer than one milli-unit is not representable: refused, not rounded
-    for bad in ("0.0001", "1.0000001Mi", "5u"):
+    # ... and so is one whose milli-units overflow: a long digit string with a large suffix must not wrap around 128 bits
+    # on its way to the range check, nor a long fraction with a negative exponent
+    for bad in ("0.0001", "1.0000001Mi", "5u", "99999999999999999999Ei", "999999999999999999999999999999e24", "1.000000000000000000000000000001e-24"):
         ctx = dict(base, eviction_hard={"memory.available": bad})
         try:
             L.dll.kg_catalog_free(L.catalog_build_ec2(abi.build_ec2_catalog(infos[:4], ctx, ctx["limits"], ctx["bandwidth"], oz)))
             raise AssertionError("expected KG_EUNSUPPORTED for %r" % bad)
+        except AssertionError:
+            raise
         except Exception as e:  # noqa: BLE001
             assert "EUNSUPPORTED" in str(e) and "milli" in str(e), (bad, e)
     # behaviour: a Solve over the natively built catalog == a Solve over the uploaded oracle catalog

@@ -21,6 +21,8 @@ def _both(L, prob, hcat):
             L.dll.kg_cluster_free(hcl)
     d = diff_results(a.decode(), b.decode())
     assert d == "", d
+    d = diff_results(prob.run_oracle().decode(), b.decode())  # ... and with the CPU oracle, not only with the other entry point
+    assert d == "", d
     assert (a.res.visited_claims, a.res.visited_claim_types, a.res.new_claim_scans, a.res.visited_existing, a.res.relaxations) == \
            (b.res.visited_claims, b.res.visited_claim_types, b.res.new_claim_scans, b.res.visited_existing, b.res.relaxations)
     return a, b
@@ -56,3 +58,40 @@ def test_solve_noalloc_matches_solve():
         L.set_collect_stats(True)
         L.dll.kg_catalog_free(hcat)
         L.close()
+
+
+def test_two_contexts_share_one_gpus_array():
+    """Two contexts on ONE GPU call kg_solve_noalloc at the same time (each under its own context lock): the library
+    serialises them on the device's scratch mutex, so neither overwrites the other's tables mid-kernel."""
+    import threading
+    zones, types = catalog776()
+    fams = families(types)
+    probs = [Problem(types, wl.mixed_pods(1500, 11, zones, fams), [wl.default_nodepool()]),
+             Problem(types, wl.mixed_pods(1200, 23, zones, fams), [wl.default_nodepool()])]
+    want = [p.run_oracle().decode() for p in probs]
+    libs = [lib.Library(device=0), lib.Library(device=0)]
+    cats = [L.catalog_upload(p.cat) for L, p in zip(libs, probs)]
+    errors = []
+
+    def worker(k):
+        try:
+            L, prob = libs[k], probs[k]
+            L.set_collect_stats(False)
+            for _ in range(6):
+                r = L.solve([cats[k]], None, prob.pods, prob.nodepools, prob.n_pods, noalloc=True)
+                d = diff_results(want[k], r.decode())
+                assert d == "", d
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)[:500]))
+
+    try:
+        ts = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errors, errors
+    finally:
+        for L, h in zip(libs, cats):
+            L.dll.kg_catalog_free(h)
+            L.close()
