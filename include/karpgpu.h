@@ -367,13 +367,17 @@ typedef struct {
   double device_ms_total, host_compile_ms_total;
   uint64_t device_bytes_resident;
   uint64_t catalog_words_patched; /* 8-byte words of resident catalogs rewritten in place by kg_catalog_update_offerings */
-  uint64_t wave_solves;           /* kg_solve calls served by the single-wave kernel (batches without topology groups / existing nodes / minValues) */
+  uint64_t wave_solves;           /* kg_solve calls served by a barrier-free wave kernel (batches without topology groups / existing nodes / minValues) */
   /* the last kg_consolidate_single / _multi call of the context */
   uint64_t cons_simulations;      /* simulations run on the device (units with reschedulable pods) */
   double cons_algorithmic_bytes;  /* SURVEY.md 8(d) bytes summed over the simulations; 0 unless the visit counters are on */
   double cons_prepass_ms, cons_sim_init_ms, cons_simulate_ms, cons_gather_ms; /* HIP-event time per kernel group */
   uint64_t cons_state_bytes_per_simulation;
   uint64_t cons_plans_built, cons_plan_hits;  /* consolidation rounds that prepared their snapshot / found it prepared */
+  /* of the wave_solves, those served by the speculative multi-wave kernel (several pods of the Queue in flight, retired in
+   * Queue order), and over them: pods committed straight from their speculative evaluation, window claims evaluated again at
+   * a pod's turn, pods rescanned at their turn (their claim took another pod meanwhile) */
+  uint64_t spec_solves, spec_fast_commits, spec_challengers, spec_rescans;
 } kg_stats;
 
 typedef struct kg_ctx kg_ctx;
@@ -391,7 +395,9 @@ int32_t kg_stats_get(kg_ctx* ctx, kg_stats* out);
  * the counters off, a Solve without topology groups, existing nodes and minValues NodePools is served by the single-wave
  * kernel (kg_stats.wave_solves counts them), every other one by the workgroup kernel: same results.  The other bits are
  * debugging aids: 2 = phase timers to stderr, 4 / 8 = 1024 / 512 threads for the workgroup kernel, 16 = never use the
- * wave-local / single-wave paths, 32 = per-wave cycle accounting to stderr.  Consolidation rounds honour 2 (every simulation
+ * wave-local / single-wave paths, 32 = per-wave cycle accounting to stderr, 64 = never use the speculative multi-wave
+ * kernel (such batches then run on the single-wave kernel), 128 = the speculative kernel evaluates every pod again at its
+ * turn (no verdict of the speculative evaluation is used).  Consolidation rounds honour 2 (every simulation
  * leaves time stamps; staging time and a per-pod fit of the batch go to stderr) and 32 (a debug instantiation of the batch
  * kernel, cycles per phase and wave summed over the batch); set them before the first round on a snapshot (plans are cached). */
 int32_t kg_set_collect_stats(kg_ctx* ctx, int32_t enabled);

@@ -8,7 +8,7 @@
 #include <vector>
 
 #include "hal.hpp"
-#include "solve_wave.hpp"
+#include "solve_spec.hpp"
 
 namespace kg {
 
@@ -93,6 +93,22 @@ __global__ void __launch_bounds__(64) k_solve_wave(DevProblem Pin, const SimStat
   const KG_CONST DevProblem* Pk = (const KG_CONST DevProblem*)__builtin_amdgcn_kernarg_segment_ptr();
   const KG_CONST SimState* Sk = (const KG_CONST SimState*)(sims + blockIdx.x);
   solve_wave<DBG>(P, S, Pk, Sk, sh, pool, nqueue[blockIdx.x]);
+}
+
+// k_solve_spec: W waves of one workgroup = one Scheduler.Solve, W pods in flight (solve_spec.hpp: same batches as k_solve_wave,
+// minus those with negative operators on custom label keys)
+constexpr uint32_t KG_SPEC_POOL_WORDS = (160 * 1024 - (uint32_t)sizeof(SharedBase) - (uint32_t)sizeof(SpecCtl)) / 8 - 4;
+template <int W, bool DBG>
+__global__ void __launch_bounds__(64 * W) k_solve_spec(DevProblem Pin, const SimState* sims, const uint32_t* nqueue) {
+  __shared__ SharedBase sh;
+  __shared__ SpecCtl ctl;
+  __shared__ __attribute__((aligned(16))) uint64_t pool[KG_SPEC_POOL_WORDS];
+  static_assert(sizeof(SharedBase) + sizeof(SpecCtl) + sizeof(uint64_t) * KG_SPEC_POOL_WORDS <= 160 * 1024, "LDS of one CU");
+  const DevProblem& P = Pin;
+  const SimState S = sims[blockIdx.x];
+  const KG_CONST DevProblem* Pk = (const KG_CONST DevProblem*)__builtin_amdgcn_kernarg_segment_ptr();
+  const KG_CONST SimState* Sk = (const KG_CONST SimState*)(sims + blockIdx.x);
+  solve_spec<W, DBG>(P, S, Pk, Sk, sh, ctl, pool, KG_SPEC_POOL_WORDS, nqueue[blockIdx.x]);
 }
 
 // k_sim_init: one workgroup per simulation copies the pristine state image into its slot and applies the patches
@@ -328,6 +344,19 @@ void launch_solve_wave(const DevProblem& P, const SimState* sims, int nsims, con
   if (P.stats & 8) hipLaunchKernelGGL((k_solve_wave<true>), dim3(nsims), dim3(64), 0, t_stream, P, sims, nqueue);
   else hipLaunchKernelGGL((k_solve_wave<false>), dim3(nsims), dim3(64), 0, t_stream, P, sims, nqueue);
   ck(hipGetLastError(), "solve (wave) launch");
+  *ms = t.stop();
+}
+void launch_solve_spec(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int waves, float* ms) {
+  Timer t("kg solve (k_solve_spec)");
+  if (P.stats & 8) {  // (debug: per-wave cycle accounting)
+    if (waves >= 8) hipLaunchKernelGGL((k_solve_spec<8, true>), dim3(nsims), dim3(512), 0, t_stream, P, sims, nqueue);
+    else hipLaunchKernelGGL((k_solve_spec<4, true>), dim3(nsims), dim3(256), 0, t_stream, P, sims, nqueue);
+  }
+  else if (waves >= 8) hipLaunchKernelGGL((k_solve_spec<8, false>), dim3(nsims), dim3(512), 0, t_stream, P, sims, nqueue);
+  else if (waves >= 6) hipLaunchKernelGGL((k_solve_spec<6, false>), dim3(nsims), dim3(384), 0, t_stream, P, sims, nqueue);
+  else if (waves >= 4) hipLaunchKernelGGL((k_solve_spec<4, false>), dim3(nsims), dim3(256), 0, t_stream, P, sims, nqueue);
+  else hipLaunchKernelGGL((k_solve_spec<2, false>), dim3(nsims), dim3(128), 0, t_stream, P, sims, nqueue);
+  ck(hipGetLastError(), "solve (speculative) launch");
   *ms = t.stop();
 }
 void launch_sim_init(const DevProblem& P, const SimBatch& B, float* ms) {

@@ -66,6 +66,9 @@ void launch_solve(const DevProblem& Pin, const SimState* sims, int nsims, const 
 void launch_solve_wave(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, float* ms) {
   launch_solve(P, sims, nsims, nqueue, 256, ms, false);
 }
+void launch_solve_spec(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int, float* ms) {
+  launch_solve(P, sims, nsims, nqueue, 256, ms, false);
+}
 void launch_sim_init(const DevProblem& P, const SimBatch& B, float* ms) {
   for (int i = 0; i < B.nsims; ++i) {
     for (uint32_t t = 0; t < 64; ++t) sim_init_copy(B, (uint32_t)i, t, 64);

@@ -42,6 +42,8 @@ void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms);
 void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue_dev, int block, float* ms, bool batch = false);
 // one wave per Solve (device build; the emulation runs the workgroup loop): see Compiled::wave_ok for when it applies
 void launch_solve_wave(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue_dev, float* ms);
+// `waves` waves of one workgroup per Solve, that many pods in flight (solve_spec.hpp); see Compiled::spec_ok
+void launch_solve_spec(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue_dev, int waves, float* ms);
 // consolidation batches: k_sim_init (state slots from the pristine image + per-simulation patches), k_sim_gather
 void launch_sim_init(const DevProblem& P, const SimBatch& B, float* ms);
 void launch_sim_gather(const DevProblem& P, const SimBatch& B, const SimState* sims, float* ms);

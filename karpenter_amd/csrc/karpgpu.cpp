@@ -353,6 +353,7 @@ struct Compiled {
   size_t state_bytes = 0, state_init_bytes = 0;  // whole state slot / its initialised prefix (the only part uploaded for a Solve)
   uint32_t qcap = 0;
   bool wave_ok = false;  // the single-wave solve applies (no topology groups, no existing nodes, no minValues, tables fit LDS)
+  bool spec_ok = false;  // ... and so does the speculative multi-wave one: no requirement set holds a negative operator on a custom label key
   std::vector<uint32_t> queue_order, pod_variant0;  // pods in Queue order; initial variant of every pod
   // simulations: what every bound pod of the universe adds to the initial topology counts (it is taken out of the
   // simulations that reschedule it): gcount index g * 64 + d, or 0x80000000 | hcount index
@@ -835,6 +836,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   }
   const int N = (int)nodes.size(), NW = std::max((N + 63) / 64, 1);
   C.N = N;
+  bool neg_custom = false;
   for (int s = 0; s < S; ++s) {
     rs_off[s] = (uint32_t)e_slot.size();
     rs_host_off[s] = (uint32_t)rs_host_nodes.size();
@@ -848,6 +850,10 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
         continue;
       }
       const int a = find_slot(C, q.key);
+      // NotIn / DoesNotExist on a label key that is not well known: a NodeClaim that lacks the key rejects pods that select
+      // on it until such a pod has joined -- the one case where NodeClaim.Add can BECOME feasible, which the speculative
+      // kernel's argument excludes (solve_spec.hpp)
+      if (!((wk_slots >> a) & 1) && ((q.compl_ && !q.vals.empty()) || (!q.compl_ && q.vals.empty() && !q.has_gt && !q.has_lt))) neg_custom = true;
       e_slot.push_back((uint8_t)a);
       e_meta.push_back(rm_make(q.compl_, q.has_gt ? gt_idx(a, q.gt) : 0, q.has_lt ? lt_idx(a, q.lt) : 0));
       e_bits.push_back((uint32_t)rs_bits.size());
@@ -1355,9 +1361,12 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
               CT.n_zone_vals * CT.n_ct_vals <= (uint32_t)KG_OFFROWS;
     for (int sp = 0; sp < nspec; ++sp) ok = ok && ktwv_n[C.spec_slot[sp]] <= KG_SPV;
     C.wave_ok = ok;
+    // (... and a batch small enough that its NodeClaims' prefilter records stay in LDS: the speculative evaluation tests every
+    // claim, where the single-wave kernel stops at the first feasible one)
+    C.spec_ok = ok && !neg_custom && P <= 16384;
   }
   D.TWP = TWP; D.NV = NV; D.stats = (stats ? 1 : 0) | (ctx->collect_timers ? 2 : 0) | (ctx->no_fast_path ? 4 : 0) | (ctx->wave_timers ? 8 : 0) |
-            (ctx->collect_timers && sim_mode ? 16 : 0);  // (DevProblem::stats bit 2 = no wave-local evaluation, bit 4 = simulations leave their time stamps)
+            (ctx->collect_timers && sim_mode ? 16 : 0) | (ctx->spec_serial ? 64 : 0);  // (DevProblem::stats bit 2 = no wave-local evaluation, bit 4 = simulations leave their time stamps)
   for (int r = 0; r < R; ++r) {
     const uint32_t g = C.act_res[r];
     const uint32_t* toff = (const uint32_t*)(CT.image.bytes.data() + CT.o_thr_off);
@@ -1569,6 +1578,7 @@ int32_t kg_init(int32_t device, kg_ctx** out) {
   if (!err.empty()) { fprintf(stderr, "kg_init: %s\n", err.c_str()); return KG_EDEVICE; }
   auto* ctx = new kg_ctx();
   ctx->device = dev;
+  if (const char* sw = getenv("KG_SPEC_WAVES")) { const int w = atoi(sw); if (w >= 2 && w <= 8) ctx->spec_waves = w; }  // (measurements only)
   try {
     hal::use_device(dev, nullptr);
     ctx->stream = hal::stream_create();
@@ -1633,6 +1643,8 @@ int32_t kg_set_collect_stats(kg_ctx* ctx, int32_t enabled) {
   ctx->collect_stats = (enabled & 1) != 0;
   ctx->collect_timers = (enabled & 2) != 0;
   ctx->no_fast_path = (enabled & 16) != 0;
+  ctx->no_spec = (enabled & 64) != 0;
+  ctx->spec_serial = (enabled & 128) != 0;
   ctx->wave_timers = (enabled & 32) != 0;
   ctx->block_threads = (enabled & 4) ? 1024 : ((enabled & 8) ? 512 : 256);  // debugging aid: per-phase ticks of k_solve printed to stderr
   return KG_OK;
@@ -1896,7 +1908,9 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
   hal::launch_prepass(C->dp, C->pre, &ms_pre);
   const uint32_t* nq_dev = (const uint32_t*)((uint8_t*)C->state_dev.ptr + C->o_nqueue);
   const bool use_wave = C->wave_ok && !stats && !ctx->collect_timers && !ctx->no_fast_path;
-  if (use_wave) { hal::launch_solve_wave(C->dp, (const SimState*)C->sims_dev.ptr, 1, nq_dev, &ms_solve); ctx->stats.wave_solves += 1; }
+  const bool use_spec = use_wave && C->spec_ok && !ctx->no_spec;
+  if (use_spec) { hal::launch_solve_spec(C->dp, (const SimState*)C->sims_dev.ptr, 1, nq_dev, ctx->spec_waves, &ms_solve); ctx->stats.wave_solves += 1; ctx->stats.spec_solves += 1; }
+  else if (use_wave) { hal::launch_solve_wave(C->dp, (const SimState*)C->sims_dev.ptr, 1, nq_dev, &ms_solve); ctx->stats.wave_solves += 1; }
   else hal::launch_solve(C->dp, (const SimState*)C->sims_dev.ptr, 1, nq_dev, ctx->block_threads, &ms_solve);
   ctx->stats.kernel_launches += 3;
   // ---- results
@@ -1929,14 +1943,14 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
     fprintf(stderr, "[kg timers] survivors %llu rounds %llu false_pos %llu passes %llu\n", (unsigned long long)counters[20],
             (unsigned long long)counters[21], (unsigned long long)counters[22], (unsigned long long)counters[23]);
   }
-  if (ctx->wave_timers && use_wave) {
+  if (ctx->wave_timers && use_wave && !use_spec) {
     static const char* sec[] = {"pop + pod context", "prefilter", "row load + group end", "NodeClaim.Add", "commit", "refresh after a false survivor", "new NodeClaim", "loop back"};
     for (int k = 0; k < 8; ++k) fprintf(stderr, "[kg wave] %-32s %9.0f kcycles\n", sec[k], counters[64 + k] / 1e3);
     fprintf(stderr, "[kg wave] prefilter steps %llu, survivors %llu, exact evaluations %llu\n", (unsigned long long)counters[72], (unsigned long long)counters[73],
             (unsigned long long)counters[74]);
     static const char* nsec[] = {"limits + template row", "NodeClaim.Add (fresh)", "row stores", "headroom / subtractMax", "scan order"};
     for (int k = 0; k < 5; ++k) fprintf(stderr, "[kg wave]   new NodeClaim: %-24s %9.0f kcycles\n", nsec[k], counters[80 + k] / 1e3);
-  } else if (ctx->wave_timers) {
+  } else if (ctx->wave_timers && !use_spec) {
     static const char* ph[] = {"prefilter", "wave-local Add", "commit", "fresh commit", "fresh setup", "workgroup Add", "nodes", "relax / ctx"};
     for (int k = 0; k < 8; ++k) {
       fprintf(stderr, "[kg waves] %-15s work / wait kcycles:", ph[k]);
@@ -1947,6 +1961,28 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
       fprintf(stderr, "[kg waves] slot %2d kcycles:", k);
       for (int w = 0; w < ctx->block_threads / 64; ++w) fprintf(stderr, "  %8.0f", counters[64 + w * 32 + k] / 1e3);
       fprintf(stderr, "\n");
+    }
+  }
+  if (use_spec) {
+    if (header[15]) throw std::runtime_error("speculative solve: a wave gave up waiting (code " + std::to_string(header[15]) + "); results discarded");
+    ctx->stats.spec_fast_commits += counters[48]; ctx->stats.spec_challengers += counters[49]; ctx->stats.spec_rescans += counters[50];
+    if (getenv("KG_SPEC_DEBUG") || ctx->wave_timers)
+      fprintf(stderr, "[kg spec] commits from speculation %llu, challengers %llu, rescans %llu, new NodeClaims %llu, failures %llu, exact evaluations %llu, "
+              "new NodeClaims / failures evaluated again at the turn %llu; LDS: %llu prefilter records, pool %llu of %llu words before them\n",
+              (unsigned long long)counters[48], (unsigned long long)counters[49], (unsigned long long)counters[50], (unsigned long long)counters[51],
+              (unsigned long long)counters[52], (unsigned long long)counters[53], (unsigned long long)counters[54], (unsigned long long)counters[55],
+              (unsigned long long)counters[56], (unsigned long long)counters[57]);
+    if (ctx->wave_timers) {
+      static const char* nm[] = {"wait: queue entry", "speculative evaluation", "wait: turn", "token: commit from speculation", "token: after a challenger",
+                                 "token: after a rescan", "token: new NodeClaim", "token: failure", "after the token", "tickets",
+                                 "fast: control words", "fast: window check", "fast: commit to LDS", "fast: release", "rescan: decide", "rescan: commit"};
+      const int nw = ctx->spec_waves >= 8 ? 8 : 4;
+      for (int k = 0; k < 16; ++k) {
+        fprintf(stderr, "[kg spec] %-30s", nm[k]);
+        unsigned long long tot = 0;
+        for (int w = 0; w < nw; ++w) { fprintf(stderr, " %9.0f", counters[64 + 16 * w + k] / (k == 9 ? 1.0 : 1e3)); tot += counters[64 + 16 * w + k]; }
+        fprintf(stderr, "   sum %10.0f %s\n", tot / (k == 9 ? 1.0 : 1e3), k == 9 ? "" : "kcycles");
+      }
     }
   }
   const uint32_t nclaims = header[0];

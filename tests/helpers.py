@@ -302,6 +302,12 @@ def feature_scenario(name):
             elif i % 9 == 2:
                 p["required_terms"] = [[(wl.L_ZONE, "In", ["mars-1a"])], [(G + "/instance-cpu", "In", ["3"])], [(wl.L_ARCH, "In", ["arm64"])]]
         return Problem(types, pods, [wl.default_nodepool()])
+    if name == "negative_selectors_wk":
+        # the same without the custom label key: negative operators on well-known keys only, which the speculative
+        # multi-wave kernel serves (a NodeClaim never lacks a well-known key in the sense of Requirements.Compatible)
+        prob = feature_scenario("negative_selectors")
+        pods = [p for p in prob.raw_pods if not any(k == "example.com/team" for t in p.get("required_terms", []) for k, _, _ in t)]
+        return Problem(types, pods, [wl.default_nodepool()])
     if name == "negative_selectors":
         # NotIn / DoesNotExist / Exists / Lt (and Gt) in node-affinity terms, on keys every type defines, keys only some
         # types define (gpu / local nvme) and a key no type defines
@@ -343,7 +349,7 @@ def feature_scenario(name):
 
 def scenario(name):
     """Named parity scenarios shared by the emulation (CPU) and GPU test files."""
-    if name in FEATURE_SCENARIOS:
+    if name in FEATURE_SCENARIOS or name == "negative_selectors_wk":
         return feature_scenario(name)
     zones, types = catalog776()
     if name == "c3_small":

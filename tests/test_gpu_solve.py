@@ -162,34 +162,43 @@ def test_aged_context_keeps_the_wave_kernel(L):
     check_context_age(L)
 
 
-def _check_wave(L, prob, expect_wave=True):
+def _check_wave(L, prob, expect_wave=True, expect_spec=None):
     """Visit counters off = the production setting; batches without topology groups / existing nodes / minValues are
-    served by the single-wave kernel (k_solve_wave), everything else by the workgroup kernel: same results either way."""
+    served by a barrier-free wave kernel -- the speculative multi-wave one (k_solve_spec: several pods of the Queue in
+    flight, retired in Queue order) unless a requirement set holds a negative operator on a custom label key, and the
+    single-wave one (k_solve_wave; forced here with debug bit 64) -- everything else by the workgroup kernel: the same
+    results all three ways."""
     ro = prob.run_oracle()
-    L.set_collect_stats(False)
-    try:
-        w0 = L.stats().wave_solves
-        rg = prob.run_library(L)
-        took_wave = L.stats().wave_solves > w0
-    finally:
-        L.set_collect_stats(True)
-    d = diff_results(ro.decode(), rg.decode())
-    assert d == "", d
-    assert took_wave == expect_wave
+    rg = None
+    for mode in (0, 64):
+        L.set_collect_stats(mode)
+        try:
+            w0, s0 = L.stats().wave_solves, L.stats().spec_solves
+            rg = prob.run_library(L)
+            took_wave, took_spec = L.stats().wave_solves > w0, L.stats().spec_solves > s0
+        finally:
+            L.set_collect_stats(True)
+        d = diff_results(ro.decode(), rg.decode())
+        assert d == "", ("mode %d" % mode, d)
+        assert took_wave == expect_wave
+        assert not (took_spec and mode == 64)
+        if expect_spec is not None and mode == 0:
+            assert took_spec == expect_spec
+        assert ro.res.relaxations == rg.res.relaxations
     return ro, rg
 
 
 def test_wave_kernel_c1_c2(LW):
     zones, types = catalog776()
-    _check_wave(LW, Problem(types, wl.homogeneous_pods(1000), [wl.default_nodepool(capacity_types=("on-demand",))]))
+    _check_wave(LW, Problem(types, wl.homogeneous_pods(1000), [wl.default_nodepool(capacity_types=("on-demand",))]), expect_spec=True)
     fams = families(types)
-    for n, seed in ((1, 1), (2, 1), (7, 2), (55, 2), (300, 1), (2000, 42)):
-        _check_wave(LW, Problem(types, wl.mixed_pods(n, seed, zones, fams), [wl.default_nodepool()]))
+    for n, seed in ((1, 1), (2, 1), (3, 4), (7, 2), (8, 3), (9, 3), (55, 2), (300, 1), (2000, 42)):
+        _check_wave(LW, Problem(types, wl.mixed_pods(n, seed, zones, fams), [wl.default_nodepool()]), expect_spec=True)
 
 
 def test_wave_kernel_c2_full(LW):
     zones, types = catalog776()
-    ro, rg = _check_wave(LW, Problem(types, wl.mixed_pods(10000, 42, zones, families(types)), [wl.default_nodepool()]))
+    ro, rg = _check_wave(LW, Problem(types, wl.mixed_pods(10000, 42, zones, families(types)), [wl.default_nodepool()]), expect_spec=True)
     print("C2 full, single-wave kernel: device %.2f ms" % rg.res.device_ms)
 
 
@@ -197,7 +206,7 @@ def test_wave_kernel_weighted_nodepools_with_limits(LW):
     """Fresh NodeClaims from four weighted NodePools, two of them with cpu limits that run out (subtractMax), 6 zones."""
     z6, t6 = catalog776(6)
     from tests.helpers import c5_nodepools
-    _check_wave(LW, Problem(t6, wl.mixed_pods(6000, 99, z6, families(t6)), c5_nodepools()))
+    _check_wave(LW, Problem(t6, wl.mixed_pods(6000, 99, z6, families(t6)), c5_nodepools()), expect_spec=True)
 
 
 def test_wave_kernel_host_ports(LW):
@@ -223,6 +232,14 @@ def test_wave_kernel_feature_scenarios(LW, name):
     """The feature scenarios without topology groups / existing nodes run on the single-wave kernel: PreferNoSchedule
     toleration relax, OR-ed required terms, NotIn / DoesNotExist / Exists / Gt / Lt."""
     _check_wave(LW, scenario(name))
+
+
+def test_spec_kernel_negative_operators_and_relaxation(LW):
+    """The speculative multi-wave kernel on NotIn / DoesNotExist / Exists / Gt / Lt over well-known keys, and on a batch
+    whose pods fail, relax and are pushed back while other pods of the Queue are in flight."""
+    _check_wave(LW, scenario("negative_selectors_wk"), expect_spec=True)
+    _check_wave(LW, scenario("prefer_no_schedule"), expect_spec=True)
+    _check_wave(LW, scenario("two_required_terms"), expect_spec=True)
 
 
 def test_wave_kernel_scan_order_beyond_lds(LW):

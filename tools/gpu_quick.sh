@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; TAG=${1:-q}
 cd $R
 timeout -k 10 500 python -u -m pytest tests/test_gpu_solve.py tests/test_zz_no_alloc.py -m gpu -x -q --timeout 150 --timeout-method thread > $O/${TAG}_tests.log 2>&1 || { tail -15 $O/${TAG}_tests.log; exit 1; }
 tail -2 $O/${TAG}_tests.log
-timeout -k 10 300 python -u bench.py --no-consolidation --steps 20 --warmup 5 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err || { tail -5 $O/${TAG}_bench.err; exit 1; }
+KG_SPEC_DEBUG=1 timeout -k 10 300 python -u bench.py --no-consolidation --steps 20 --warmup 5 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err || { tail -5 $O/${TAG}_bench.err; exit 1; }
 python3 -c "
 import json,sys
 d=json.loads(open('$O/${TAG}_bench.json').read().strip().splitlines()[-1])
