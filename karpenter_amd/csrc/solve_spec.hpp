@@ -193,9 +193,12 @@ __device__ __forceinline__ void solve_spec(const DevProblem& P, const SimState& 
   PodCtx* const ctx_lo = (PodCtx*)(void*)((unsigned char*)&sh.ord[0][0] + ORD_PAD);
   PodCtx* const ctx_hi = (PodCtx*)(void*)(pool + off);
   if (2 * W > 8) off += (uint32_t)((2 * W - 8) * sizeof(PodCtx) / 8);
-  PodCtx* mybuf[2];
+  // (typed as LDS pointers: picked out of two arrays at run time, a generic pointer would turn every read of the pod context
+  // into a flat load -- slower, and counted on the memory counter too, so every wait for a global load would wait for them)
+  typedef __attribute__((address_space(3))) PodCtx LdsPodCtx;
+  LdsPodCtx* mybuf[2];
 #pragma unroll
-  for (int k = 0; k < 2; ++k) { const uint32_t b = 2 * wave + k; mybuf[k] = b < 8 ? ctx_lo + b : ctx_hi + (b - 8); }
+  for (int k = 0; k < 2; ++k) { const uint32_t b = 2 * wave + k; mybuf[k] = (LdsPodCtx*)(b < 8 ? ctx_lo + b : ctx_hi + (b - 8)); }
   // the merged rows of the last KG_SPEC_SLOTS tickets (slot = ticket % KG_SPEC_SLOTS): what a ticket reads at its turn when
   // it meets a claim of its log window -- the window's global stores may still be in flight
   uint64_t* const rowc = pool + off;
@@ -249,8 +252,9 @@ __device__ __forceinline__ void solve_spec(const DevProblem& P, const SimState& 
     if (!have_next) qv = ((const KG_GLOBAL uint4*)S.queue)[i % QCAP];
     const uint32_t pod = KG_UNI(qv.x), variant = KG_UNI(qv.y), qz = KG_UNI(qv.z), qw = KG_UNI(qv.w);
     cur ^= 1;
-    if (!have_next) ctx_fetch_image(P, *mybuf[cur], lane, pod, variant);
-    const PodCtx& pc = *mybuf[cur];
+    LdsPodCtx* const pcl = cur ? mybuf[1] : mybuf[0];
+    if (!have_next) ctx_fetch_image(P, *(PodCtx*)pcl, lane, pod, variant);
+    const PodCtx& pc = *(const PodCtx*)pcl;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the context words other lanes stored)
     // ---- the wave's next ticket: its Queue entry, context image and requests are requested now and land in the other
     // buffer when this ticket is retired
@@ -752,7 +756,7 @@ __device__ __forceinline__ void solve_spec(const DevProblem& P, const SimState& 
     // ---- the next ticket's context -> the other buffer
     have_next = next_ok;
     if (next_ok) {
-      uint64_t* dst = (uint64_t*)mybuf[cur ^ 1];
+      __attribute__((address_space(3))) uint64_t* dst = (__attribute__((address_space(3))) uint64_t*)(cur ? mybuf[0] : mybuf[1]);
       const unsigned long long nb = __ballot(n_rq != 0);
       uint64_t w0 = iw[0];
       if (lane < KG_MAXR) w0 = (uint64_t)n_rq;          // words 0..7: the pod's requests
