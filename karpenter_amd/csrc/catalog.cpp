@@ -185,7 +185,8 @@ void build_catalog_tables(kg_ctx* ctx, kg_catalog* cat) {
   {
     std::vector<uint32_t> idx(T);
     for (uint32_t t = 0; t < T; ++t) idx[t] = t;
-    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return cat->types[a].name < cat->types[b].name; });
+    // (same-named types of a merged view keep their index order: what a stable sort by name gives)
+    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return cat->types[a].name != cat->types[b].name ? cat->types[a].name < cat->types[b].name : a < b; });
     for (uint32_t i = 0; i < T; ++i) name_rank[idx[i]] = (uint16_t)i;
   }
   Arena& A = C.image;

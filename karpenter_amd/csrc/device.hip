@@ -111,6 +111,41 @@ __global__ void __launch_bounds__(64 * W) k_solve_spec(DevProblem Pin, const Sim
   solve_spec<W, DBG>(P, S, Pk, Sk, sh, ctl, pool, KG_SPEC_POOL_WORDS, nqueue[blockIdx.x]);
 }
 
+// k_price_order_truncate: one workgroup per new NodeClaim (solve_core.hpp: InstanceTypes.OrderByPrice / Truncate)
+__global__ void __launch_bounds__(256) k_price_order_truncate(DevProblem P, const SimState* sims, TruncArgs X) {
+  __shared__ double price[KG_TRUNC_T];
+  __shared__ uint16_t nrank[KG_TRUNC_T];
+  __shared__ uint32_t nset;
+  const SimState S = sims[0];
+  const uint32_t c = blockIdx.x, tid = threadIdx.x, T = (uint32_t)P.T;
+  if (c >= S.header[0] || T > KG_TRUNC_T) return;
+  uint64_t zmask, ctmask;
+  claim_offering_masks(P, S, c, &zmask, &ctmask);
+  if (tid == 0) nset = 0;
+  __syncthreads();
+  uint32_t mine = 0;
+  for (uint32_t t = tid; t < T; t += 256) {
+    const bool in = (S.c_mask[(size_t)(t >> 6) * P.Cmax + c] >> (t & 63)) & 1;
+    price[t] = in ? type_cheapest(X, t, zmask, ctmask) : -1.0;  // (prices are never negative: -1 = not an option of this claim)
+    nrank[t] = X.name_rank[t];
+    mine += in;
+  }
+  if (mine) atomicAdd(&nset, mine);
+  __syncthreads();
+  for (uint32_t t = tid; t < T; t += 256) {
+    const double pt = price[t];
+    if (pt < 0) continue;
+    const uint32_t rt = nrank[t];
+    uint32_t rank = 0;
+    for (uint32_t u = 0; u < T; ++u) {
+      const double pu = price[u];
+      rank += (pu >= 0 && price_before(pu, nrank[u], pt, rt)) ? 1u : 0u;
+    }
+    if (rank < X.max_types) X.rec[(size_t)c * X.rec_words + 4 + rank] = t;
+  }
+  trunc_pack(P, S, X, c, tid, 256, nset);
+}
+
 // k_sim_init: one workgroup per simulation copies the pristine state image into its slot and applies the patches
 __global__ void __launch_bounds__(256) k_sim_init(DevProblem P, SimBatch B) {
   sim_init_copy(B, blockIdx.x, threadIdx.x, blockDim.x);
@@ -358,6 +393,11 @@ void launch_solve_spec(const DevProblem& P, const SimState* sims, int nsims, con
   else hipLaunchKernelGGL((k_solve_spec<2, false>), dim3(nsims), dim3(128), 0, t_stream, P, sims, nqueue);
   ck(hipGetLastError(), "solve (speculative) launch");
   *ms = t.stop();
+}
+void launch_truncate(const DevProblem& P, const SimState* sims, const TruncArgs& X, int max_claims) {
+  // (no timer of its own: it runs behind the solve kernel on the same stream, and the decode's first copy waits for both)
+  if (max_claims > 0) hipLaunchKernelGGL(k_price_order_truncate, dim3(max_claims), dim3(256), 0, t_stream, P, sims, X);
+  ck(hipGetLastError(), "truncate launch");
 }
 void launch_sim_init(const DevProblem& P, const SimBatch& B, float* ms) {
   Timer t("kg k_sim_init");

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <vector>
 
 #include "hal.hpp"
 
@@ -68,6 +69,29 @@ void launch_solve_wave(const DevProblem& P, const SimState* sims, int nsims, con
 }
 void launch_solve_spec(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int, float* ms) {
   launch_solve(P, sims, nsims, nqueue, 256, ms, false);
+}
+void launch_truncate(const DevProblem& P, const SimState* sims, const TruncArgs& X, int max_claims) {
+  const SimState& S = sims[0];
+  const uint32_t T = (uint32_t)P.T;
+  if (T > KG_TRUNC_T) return;
+  std::vector<double> price(T);
+  for (uint32_t c = 0; c < S.header[0] && c < (uint32_t)max_claims; ++c) {
+    uint64_t zmask, ctmask;
+    claim_offering_masks(P, S, c, &zmask, &ctmask);
+    uint32_t nset = 0;
+    for (uint32_t t = 0; t < T; ++t) {
+      const bool in = (S.c_mask[(size_t)(t >> 6) * P.Cmax + c] >> (t & 63)) & 1;
+      price[t] = in ? type_cheapest(X, t, zmask, ctmask) : -1.0;
+      nset += in;
+    }
+    for (uint32_t t = 0; t < T; ++t) {
+      if (price[t] < 0) continue;
+      uint32_t rank = 0;
+      for (uint32_t u = 0; u < T; ++u) rank += (price[u] >= 0 && price_before(price[u], X.name_rank[u], price[t], X.name_rank[t])) ? 1u : 0u;
+      if (rank < X.max_types) X.rec[(size_t)c * X.rec_words + 4 + rank] = t;
+    }
+    trunc_pack(P, S, X, c, 0, 1, nset);
+  }
 }
 void launch_sim_init(const DevProblem& P, const SimBatch& B, float* ms) {
   for (int i = 0; i < B.nsims; ++i) {

@@ -44,6 +44,8 @@ void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const ui
 void launch_solve_wave(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue_dev, float* ms);
 // `waves` waves of one workgroup per Solve, that many pods in flight (solve_spec.hpp); see Compiled::spec_ok
 void launch_solve_spec(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue_dev, int waves, float* ms);
+// one workgroup per NodeClaim of the Solve that just ran on this stream: price-ordered, truncated type lists (TruncArgs)
+void launch_truncate(const DevProblem& P, const SimState* sims, const TruncArgs& X, int max_claims);
 // consolidation batches: k_sim_init (state slots from the pristine image + per-simulation patches), k_sim_gather
 void launch_sim_init(const DevProblem& P, const SimBatch& B, float* ms);
 void launch_sim_gather(const DevProblem& P, const SimBatch& B, const SimState* sims, float* ms);

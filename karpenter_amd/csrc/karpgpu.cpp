@@ -364,6 +364,10 @@ struct Compiled {
   uint32_t thash_mask = 0;
   size_t o_nreq, o_creq, o_chead, o_chstamp, o_cmask, o_cbits, o_cmeta, o_cnpods, o_ctmpl, o_order, o_remaining, o_gcount, o_gdom, o_gpos, o_hcount, o_hpos, o_queue,
       o_podkind, o_excl, o_podindex, o_podreason, o_scratch, o_ordg, o_header, o_counters, o_nqueue;
+  // price-ordered truncation on the device (k_price_order_truncate): records of the first trunc_claims NodeClaims behind the state
+  size_t o_trec = 0;
+  uint32_t trunc_words = 0, trunc_claims = 0, trunc_max = 0;
+  TruncArgs trunc{};
   bool fixed = false;  // the device buffers are carved from a FixedArena (kg_solve_noalloc): nothing to give back
   ~Compiled() {
     // (back to the context's pool; every path that builds or drops a Compiled holds ctx->mu)
@@ -1463,12 +1467,29 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   C.state_image = std::move(SA.bytes);
   C.o_crow = C.state_bytes;
   if (sim_mode) return Cp;  // the caller lays out one slot per simulation
-  C.state_dev.bytes = C.state_bytes + (C.wave_ok ? (size_t)Cmax * 896 : 8);  // claim rows of the single-wave solve (KG_ROW_WORDS * 8)
+  size_t tail = C.wave_ok ? (size_t)Cmax * 896 : 8;  // claim rows of the single-wave solve (KG_ROW_WORDS * 8)
+  // Results.TruncateInstanceTypes on the device: NodePools without minValues (SatisfiesMinValues may widen the list: host),
+  // a catalog whose prices fit the kernel's LDS
+  const int max_types = in.nps->max_instance_types;
+  if (max_types > 0 && max_types <= 1024 && tmpl_minv_mask == 0 && T <= (int)KG_TRUNC_T) {
+    C.trunc_max = (uint32_t)max_types;
+    C.trunc_words = trunc_rec_words(C.trunc_max, Ka, C.Wa, R);
+    C.trunc_claims = (uint32_t)std::min(Cmax, 8192);
+    C.o_trec = (C.state_bytes + tail + 255) & ~size_t(255);
+    tail = C.o_trec - C.state_bytes + (size_t)C.trunc_claims * C.trunc_words * 4;
+  }
+  C.state_dev.bytes = C.state_bytes + tail;
   if (in.fixed) { C.state_dev.ptr = in.fixed->take(C.state_dev.bytes, "solve state"); C.state_cap = C.state_dev.bytes; }
   else C.state_dev.ptr = ctx->pool_take(C.state_dev.bytes, &C.state_cap);
   hal::h2d(C.state_dev.ptr, C.state_image.data(), C.state_init_bytes);
   hal::dzero((uint8_t*)C.state_dev.ptr + C.state_init_bytes, C.state_bytes - C.state_init_bytes);
   C.sim = sim_at(C, (uint8_t*)C.state_dev.ptr);
+  if (C.trunc_claims) {
+    TruncArgs& X = C.trunc;
+    X.off_begin = (const uint32_t*)cptr(CT.o_off_begin); X.off_zone = (const uint16_t*)cptr(CT.o_off_zone); X.off_ct = (const uint16_t*)cptr(CT.o_off_ct);
+    X.off_price = (const double*)cptr(CT.o_off_price); X.off_avail = (const uint8_t*)cptr(CT.o_off_avail); X.name_rank = (const uint16_t*)cptr(CT.o_name_rank);
+    X.max_types = C.trunc_max; X.rec = (uint32_t*)((uint8_t*)C.state_dev.ptr + C.o_trec); X.rec_words = C.trunc_words;
+  }
   SimState& St = C.sim;
   C.sims_dev.bytes = sizeof(SimState);
   if (in.fixed) { C.sims_dev.ptr = in.fixed->take(sizeof(SimState), "state descriptor"); C.sims_cap = sizeof(SimState); }
@@ -1913,6 +1934,9 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
   else if (use_wave) { hal::launch_solve_wave(C->dp, (const SimState*)C->sims_dev.ptr, 1, nq_dev, &ms_solve); ctx->stats.wave_solves += 1; }
   else hal::launch_solve(C->dp, (const SimState*)C->sims_dev.ptr, 1, nq_dev, ctx->block_threads, &ms_solve);
   ctx->stats.kernel_launches += 3;
+  // InstanceTypes.OrderByPrice / Truncate per new NodeClaim, behind the solve kernel on the same stream (no host round trip
+  // in between: the kernel reads the claim count from the state's header)
+  if (C->trunc_claims) { hal::launch_truncate(C->dp, (const SimState*)C->sims_dev.ptr, C->trunc, (int)C->trunc_claims); ctx->stats.kernel_launches += 1; }
   // ---- results
   phase.emplace("kg_solve: decode");
   const int P = C->P, Cmax = C->Cmax, TW = C->TW, R = C->R, Ka = C->Ka;
@@ -1921,11 +1945,20 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
   std::vector<uint32_t> pod_reason(std::max(P, 1)), header(16);
   std::vector<uint64_t> counters(64 + 16 * 32);
   auto sp = [&](size_t off) { return (uint8_t*)C->state_dev.ptr + off; };
-  hal::d2h(pod_kind.data(), sp(C->o_podkind), P);
-  hal::d2h(pod_index.data(), sp(C->o_podindex), (size_t)P * 4);
-  hal::d2h(pod_reason.data(), sp(C->o_podreason), (size_t)P * 4);
-  hal::d2h(header.data(), sp(C->o_header), 64);
-  hal::d2h(counters.data(), sp(C->o_counters), counters.size() * 8);
+  {
+    // header + counters lie next to each other in the state image, and so do the three per-pod result arrays: two copies
+    check(C->o_counters >= C->o_header + 64 && C->o_counters - C->o_header <= 256, "state layout: header / counters");
+    std::vector<uint8_t> hc((C->o_counters - C->o_header) + counters.size() * 8);
+    hal::d2h(hc.data(), sp(C->o_header), hc.size());
+    memcpy(header.data(), hc.data(), 64);
+    memcpy(counters.data(), hc.data() + (C->o_counters - C->o_header), counters.size() * 8);
+    check(C->o_podindex > C->o_podkind && C->o_podreason > C->o_podindex, "state layout: pod results");
+    std::vector<uint8_t> pr((C->o_podreason - C->o_podkind) + (size_t)std::max(P, 1) * 4);
+    hal::d2h(pr.data(), sp(C->o_podkind), pr.size());
+    memcpy(pod_kind.data(), pr.data(), P);
+    memcpy(pod_index.data(), pr.data() + (C->o_podindex - C->o_podkind), (size_t)P * 4);
+    memcpy(pod_reason.data(), pr.data() + (C->o_podreason - C->o_podkind), (size_t)P * 4);
+  }
   if (ctx->collect_timers) {
     static const char* names[] = {"pop+ctx", "nodes", "prefilter", "load rows", "merge(+topology)", "type filter", "pick", "commit", "fresh setup", "relax"};
     for (int i = 0; i < 10; ++i) fprintf(stderr, "[kg timers] %-15s %10.3f ms\n", names[i], counters[8 + i] / 1e5);
@@ -1990,7 +2023,31 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
   std::vector<uint16_t> c_tmpl(nclaims);
   std::vector<uint64_t> c_mask((size_t)TW * nclaims), c_bits((size_t)C->Wa * nclaims);
   std::vector<int64_t> c_req((size_t)R * nclaims);
-  if (nclaims) {
+  // the NodeClaims' records as k_price_order_truncate packed them (one copy), or the state's columns (one copy per table)
+  const bool dev_trunc = C->trunc_claims != 0 && nclaims <= C->trunc_claims;
+  std::vector<uint32_t> trec, trunc_n(nclaims, 0);
+  if (nclaims && dev_trunc) {
+    const uint32_t RW = C->trunc_words, MT = C->trunc_max;
+    trec.resize((size_t)nclaims * RW);
+    hal::d2h(trec.data(), sp(C->o_trec), trec.size() * 4);
+    std::vector<uint32_t> c_stamp(nclaims);
+    for (uint32_t c = 0; c < nclaims; ++c) {
+      const uint32_t* rec = trec.data() + (size_t)c * RW;
+      c_npods[c] = rec[0]; c_tmpl[c] = (uint16_t)rec[1]; c_stamp[c] = rec[2]; trunc_n[c] = rec[3];
+      const uint32_t* q = rec + 4 + MT;
+      for (int a = 0; a < Ka; ++a) c_meta[(size_t)a * nclaims + c] = q[a];
+      q += Ka;
+      for (int w = 0; w < C->Wa; ++w) c_bits[(size_t)w * nclaims + c] = (uint64_t)q[2 * w] | ((uint64_t)q[2 * w + 1] << 32);
+      q += 2 * C->Wa;
+      for (int r = 0; r < R; ++r) c_req[(size_t)r * nclaims + c] = (int64_t)((uint64_t)q[2 * r] | ((uint64_t)q[2 * r + 1] << 32));
+    }
+    for (uint32_t c = 0; c < nclaims; ++c) order[c] = c;
+    auto okey = [&](uint32_t c) -> unsigned long long {
+      if (c == header[2]) return header[5] ? ~0ull : claim_key(header[3], header[4], c);
+      return claim_key(c_npods[c], c_stamp[c], c);
+    };
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return okey(a) < okey(b); });
+  } else if (nclaims) {
     std::vector<uint32_t> c_stamp(nclaims);
     hal::d2h(c_stamp.data(), sp(C->o_order), (size_t)nclaims * 4);
     hal::d2h(c_npods.data(), sp(C->o_cnpods), (size_t)nclaims * 4);
@@ -2019,8 +2076,13 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
     const uint32_t c = order[pos];
     const Template& tp = C->templates[c_tmpl[c]];
     ClaimView cv;
-    for (int w = 0; w < TW; ++w)
-      for (uint64_t m = c_mask[(size_t)w * nclaims + c]; m; m &= m - 1) cv.types.push_back((uint32_t)(w * 64 + __builtin_ctzll(m)));
+    if (dev_trunc) {
+      const uint32_t* ids = trec.data() + (size_t)c * C->trunc_words + 4;
+      cv.types.assign(ids, ids + std::min(trunc_n[c], C->trunc_max));
+    } else {
+      for (int w = 0; w < TW; ++w)
+        for (uint64_t m = c_mask[(size_t)w * nclaims + c]; m; m &= m - 1) cv.types.push_back((uint32_t)(w * 64 + __builtin_ctzll(m)));
+    }
     // decode requirements
     std::vector<HReq> creqs;
     for (int a = 0; a < Ka; ++a) {
@@ -2057,13 +2119,15 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
       }
       return ~0ull;
     };
-    cv.zmask = has_mask(zslot);
-    cv.ctmask = has_mask(ctslot);
-    const uint64_t zidm = has_mask(zidslot);
-    if (zidslot >= 0)
-      for (int z = 0; z < 64; ++z) if (zone_zid[z] != 0xFF && !((zidm >> zone_zid[z]) & 1)) cv.zmask &= ~(1ull << z);
-    for (auto& q : tp.reqs.rs) if (q.min_values >= 0) cv.minvals.push_back({q.key, q.min_values});
-    if (nodepools->max_instance_types > 0) trunc_failed[c] = !truncate_types(catalogs[0], cv, nodepools->max_instance_types);
+    if (!dev_trunc) {  // (the device kernel derived the same masks from the claim's requirement words)
+      cv.zmask = has_mask(zslot);
+      cv.ctmask = has_mask(ctslot);
+      const uint64_t zidm = has_mask(zidslot);
+      if (zidslot >= 0)
+        for (int z = 0; z < 64; ++z) if (zone_zid[z] != 0xFF && !((zidm >> zone_zid[z]) & 1)) cv.zmask &= ~(1ull << z);
+      for (auto& q : tp.reqs.rs) if (q.min_values >= 0) cv.minvals.push_back({q.key, q.min_values});
+    }
+    if (!dev_trunc && nodepools->max_instance_types > 0) trunc_failed[c] = !truncate_types(catalogs[0], cv, nodepools->max_instance_types);
     kg_claim_out co{};
     co.nodepool = tp.index;
     co.n_pods = c_npods[c];

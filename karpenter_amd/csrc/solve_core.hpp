@@ -2084,6 +2084,72 @@ struct PrepassTables {
   struct PodCtx* pctx_out;     // [NV]
 };
 
+// ------------------------------------------------------------------ InstanceTypes.OrderByPrice / Truncate per new NodeClaim
+// (the reference's call is pkg/providers/instance/instance.go:101 with maxInstanceTypes = 60, instance.go:54;
+// comparator as re-stated by pkg/providers/instancetype/suite_test.go:414-421: price of the cheapest available offering
+// compatible with the claim's requirements, ties by name).  One workgroup per NodeClaim: a thread prices its instance
+// types over the catalog's resident offering table (IEEE doubles, compared as doubles), every type's rank is the number of
+// option types ordered before it, and the types ranked below max_types are written in order.
+constexpr uint32_t KG_TRUNC_T = 2048;  // instance types the kernel keeps prices of in LDS (catalogs beyond: ordered on the host)
+struct TruncArgs {
+  const uint32_t* off_begin;   // [T+1] offering rows per type
+  const uint16_t* off_zone;    // catalog-local zone value id
+  const uint16_t* off_ct;      // catalog-local capacity-type value id
+  const double* off_price;
+  const uint8_t* off_avail;
+  const uint16_t* name_rank;   // [T] lexicographic rank of the type's name
+  uint32_t max_types;
+  // One record per NodeClaim, rec_words 32-bit words each -- everything the host decodes of a claim, so that the results
+  // come back in one copy: [0] pods [1] template [2] order stamp [3] option types n, [4, 4 + max_types) the first
+  // min(n, max_types) catalog type indices in (price, name) order, then Ka requirement meta words, Wa value words and R
+  // requests (64-bit, low half first)
+  uint32_t* rec;
+  uint32_t rec_words;
+};
+KG_HD uint32_t trunc_rec_words(uint32_t max_types, int Ka, int Wa, int R) { return 4 + max_types + (uint32_t)Ka + 2 * (uint32_t)Wa + 2 * (uint32_t)R; }
+// the columns of claim c -> its record (thread `tid` of `nt`)
+KG_HD void trunc_pack(const DevProblem& P, const SimState& S, const TruncArgs& X, uint32_t c, uint32_t tid, uint32_t nt, uint32_t nset) {
+  uint32_t* rec = X.rec + (size_t)c * X.rec_words;
+  if (tid == 0) { rec[0] = S.c_npods[c]; rec[1] = S.c_tmpl[c]; rec[2] = S.c_stamp[c]; rec[3] = nset; }
+  uint32_t* q = rec + 4 + X.max_types;
+  for (uint32_t a = tid; a < (uint32_t)P.Ka; a += nt) q[a] = S.c_meta[(size_t)a * P.Cmax + c];
+  q += P.Ka;
+  for (uint32_t w = tid; w < (uint32_t)P.Wa; w += nt) { const uint64_t v = S.c_bits[(size_t)w * P.Cmax + c]; q[2 * w] = (uint32_t)v; q[2 * w + 1] = (uint32_t)(v >> 32); }
+  q += 2 * P.Wa;
+  for (uint32_t r = tid; r < (uint32_t)P.R; r += nt) { const uint64_t v = (uint64_t)S.c_req[(size_t)r * P.Cmax + c]; q[2 * r] = (uint32_t)v; q[2 * r + 1] = (uint32_t)(v >> 32); }
+}
+constexpr double KG_PRICE_NONE = 1.7976931348623157e308;  // math.MaxFloat64: no compatible available offering
+// allowed values of the claim on the zone / capacity-type keys over the catalog's value numbering (zone ids folded into zones)
+KG_HD void claim_offering_masks(const DevProblem& P, const SimState& S, uint32_t c, uint64_t* zmask, uint64_t* ctmask) {
+  uint64_t hm[3] = {~0ull, ~0ull, ~0ull};
+  const int sl[3] = {P.slot_zone, P.slot_ct, P.slot_zid};
+  for (int i = 0; i < 3; ++i) {
+    if (sl[i] < 0) continue;
+    const int a = P.spec_slot[sl[i]];
+    SReq r;
+    r.meta = S.c_meta[(size_t)a * P.Cmax + c];
+    r.word = (r.meta & RM_PRESENT) ? S.c_bits[(size_t)P.aoff[a] * P.Cmax + c] : 0;
+    hm[i] = has_mask1(P, a, r);
+  }
+  uint64_t zm = hm[0];
+  if (P.slot_zid >= 0)
+    for (int z = 0; z < 64; ++z) {
+      const uint8_t zid = P.zone_zid[z];
+      if (zid != 0xFF && !((hm[2] >> zid) & 1)) zm &= ~(1ull << z);
+    }
+  *zmask = zm; *ctmask = hm[1];
+}
+KG_HD double type_cheapest(const TruncArgs& X, uint32_t t, uint64_t zmask, uint64_t ctmask) {
+  double best = KG_PRICE_NONE;
+  for (uint32_t o = X.off_begin[t]; o < X.off_begin[t + 1]; ++o) {
+    if (!X.off_avail[o] || !((zmask >> X.off_zone[o]) & 1) || !((ctmask >> X.off_ct[o]) & 1)) continue;
+    const double p = X.off_price[o];
+    best = p < best ? p : best;
+  }
+  return best;
+}
+KG_HD bool price_before(double pa, uint32_t ra, double pb, uint32_t rb) { return pa < pb || (pa == pb && ra < rb); }
+
 KG_HD bool entry_has(const DevProblem& P, uint32_t e, int a, uint32_t v) {
   const uint32_t meta = P.e_meta[e];
   const uint64_t* bits = P.rs_bits + P.e_bits[e];
