@@ -43,7 +43,7 @@ struct PodClass {
 struct PodRef {
   uint32_t cls;
   uint32_t rq_off = 0, rq_n = 0;  // requests (incl. pods:1): ParsedPods::rq[rq_off .. rq_off + rq_n) -- one pool, no allocation per pod
-  std::string uid;
+  uint32_t uid_off = 0, uid_len = 0;  // ParsedPods::uid_pool[uid_off .. uid_off + uid_len): one pool, no allocation per pod
   int64_t creation;
   int node;
   bool reschedulable;
@@ -54,6 +54,8 @@ struct ParsedPods {
   std::vector<PodClass> classes;
   std::vector<PodRef> pods;
   std::vector<std::pair<uint32_t, int64_t>> rq;  // (resource id, milli) pairs of every pod's requests
+  std::string uid_pool;                            // the pods' UIDs back to back (Queue order tie-break)
+  std::string_view uid(const PodRef& p) const { return std::string_view(uid_pool).substr(p.uid_off, p.uid_len); }
   // volumes (ExistingNode.Add's volume limits): the pods' volume ids, sorted; a pod's count per CSI driver rides in `rq` as a
   // request of the internal resource "karpgpu.internal/volumes/<driver>" (additive as long as no volume is shared)
   std::vector<uint32_t> vols;

@@ -59,7 +59,9 @@ std::string PSel::canon() const {
 namespace {
 struct Sig {
   std::string s;
-  void u32(uint32_t v) { s.append((const char*)&v, 4); }
+  uint64_t h = 0;  // running hash of the words appended so far (the class table is probed with it; the string settles ties)
+  void clear() { s.clear(); h = 0x9E3779B97F4A7C15ull; }
+  void u32(uint32_t v) { s.append((const char*)&v, 4); h = (h ^ v) * 0xFF51AFD7ED558CCDull; h ^= h >> 29; }
   void range_labels(const kg_pools& p, kg_range r) { u32(r.count); for (auto& l : kgdesc::labels(p, r)) { u32(l.key); u32(l.value); } }
   void range_reqs(const kg_pools& p, kg_range r) {
     u32(r.count);
@@ -101,15 +103,21 @@ std::vector<PTerm> parse_terms(kg_ctx* ctx, const kg_pods_desc* d, kg_range r) {
 void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out, bool add_pods_one) {
   if (!d) return;
   const kg_pools& p = d->pools;
-  std::unordered_map<std::string, uint32_t> by_sig;
+  // pod classes by signature: open addressing on the running hash, the signature bytes compared on a hit
+  std::vector<std::string> class_sig;
+  std::vector<uint64_t> class_hash;
+  uint32_t tab_mask = 1023;
+  std::vector<uint32_t> tab(tab_mask + 1, UINT32_MAX);
   out->pods.reserve(d->n_pods);
   out->rq.reserve((size_t)d->n_pods * 4);
+  out->uid_pool.reserve((size_t)d->n_pods * 24);
   std::vector<int32_t> rid_of_str(p.strings.count, -1);
   std::vector<std::pair<uint32_t, int64_t>> rl;
   Sig sg;
+  sg.s.reserve(1024);
   for (uint32_t i = 0; i < d->n_pods; ++i) {
     const kg_pod& q = d->pods[i];
-    sg.s.clear();
+    sg.clear();
     sg.u32(q.ns);
     sg.range_labels(p, q.labels);
     sg.range_labels(p, q.node_selector);
@@ -132,11 +140,13 @@ void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out, bool add_po
     }
     sg.u32(q.host_ports.count);
     for (auto& h : kgdesc::span(d->host_ports, d->n_host_ports, q.host_ports, "host port range")) { sg.u32(h.ip); sg.u32((uint32_t)h.port); sg.u32(h.protocol); }
-    uint32_t cls;
-    auto it = by_sig.find(sg.s);
-    if (it != by_sig.end()) {
-      cls = it->second;
-    } else {
+    uint32_t cls = UINT32_MAX;
+    uint32_t slot = (uint32_t)(sg.h >> 20) & tab_mask;
+    for (; tab[slot] != UINT32_MAX; slot = (slot + 1) & tab_mask) {
+      const uint32_t k = tab[slot];
+      if (class_hash[k] == sg.h && class_sig[k] == sg.s) { cls = k; break; }
+    }
+    if (cls == UINT32_MAX) {
       PodClass c;
       c.ns = ctx->lab.id(kgdesc::str(p.strings, q.ns));
       for (auto& l : kgdesc::labels(p, q.labels)) c.labels.push_back({ctx->lab.id(kgdesc::str(p.strings, l.key)), ctx->lab.id(kgdesc::str(p.strings, l.value))});
@@ -162,7 +172,18 @@ void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out, bool add_po
         c.ports.push_back({h.ip == KG_NONE ? -1 : (int)ctx->lab.id(kgdesc::str(p.strings, h.ip)), h.port, (int)h.protocol});
       cls = (uint32_t)out->classes.size();
       out->classes.push_back(std::move(c));
-      by_sig.emplace(sg.s, cls);
+      class_sig.push_back(sg.s);
+      class_hash.push_back(sg.h);
+      tab[slot] = cls;
+      if (class_sig.size() * 2 > tab.size()) {  // keep the table at most half full
+        tab_mask = tab_mask * 2 + 1;
+        tab.assign(tab_mask + 1, UINT32_MAX);
+        for (uint32_t k = 0; k < class_sig.size(); ++k) {
+          uint32_t s2 = (uint32_t)(class_hash[k] >> 20) & tab_mask;
+          while (tab[s2] != UINT32_MAX) s2 = (s2 + 1) & tab_mask;
+          tab[s2] = k;
+        }
+      }
     }
     PodRef pr;
     pr.cls = cls;
@@ -195,7 +216,11 @@ void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out, bool add_po
     }
     pr.rq_off = (uint32_t)out->rq.size(); pr.rq_n = (uint32_t)rl.size();
     out->rq.insert(out->rq.end(), rl.begin(), rl.end());
-    pr.uid = std::string(kgdesc::str(p.strings, q.uid));
+    {
+      const std::string_view u = kgdesc::str(p.strings, q.uid);
+      pr.uid_off = (uint32_t)out->uid_pool.size(); pr.uid_len = (uint32_t)u.size();
+      out->uid_pool.append(u.data(), u.size());
+    }
     pr.creation = q.creation_ts;
     pr.node = q.node;
     pr.reschedulable = q.reschedulable != 0;
@@ -978,7 +1003,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
       if (a.cpu != b.cpu) return a.cpu > b.cpu;
       if (a.mem != b.mem) return a.mem > b.mem;
       if (a.creation != b.creation) return a.creation < b.creation;
-      return PP.pods[a.idx].uid < PP.pods[b.idx].uid;
+      return PP.uid(PP.pods[a.idx]) < PP.uid(PP.pods[b.idx]);
     };
     auto qkey = [&](uint32_t p) { return QKey{cpu(p), mem(p), PP.pods[p].creation, p}; };
     std::vector<QKey> keys;
@@ -999,7 +1024,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
           if (a.cpu != b.cpu) return a.cpu > b.cpu;
           if (a.mem != b.mem) return a.mem > b.mem;
           if (a.creation != b.creation) return a.creation < b.creation;
-          return cl->bound.pods[a.idx].uid < cl->bound.pods[b.idx].uid;
+          return cl->bound.uid(cl->bound.pods[a.idx]) < cl->bound.uid(cl->bound.pods[b.idx]);
         });
         cl->bound_rank.assign(nb, 0);
         for (size_t r = 0; r < nb; ++r) cl->bound_rank[bk[r].idx] = (uint32_t)r;
@@ -1329,6 +1354,9 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   std::vector<int64_t> nfree0(navail.size());
   for (size_t i = 0; i < navail.size(); ++i) nfree0[i] = navail[i] - nreq0[i];
   Arena A;
+  // (one allocation for the image: the big tables are known by now)
+  A.bytes.reserve(vctx.size() * sizeof(vctx[0]) + preq.size() * 8 + (pod_variant0.size() + queue0.size()) * 4 + rs_bits.size() * 8 + (kU.size() + kN.size()) * 8 +
+                  (gtmask.size() + ltmask.size()) * 8 + nfree0.size() * 8 + (ntol.size() + nports0.size()) * 8 + (ndom.size() + nval.size()) * 2 + (size_t)64 * 1024);
   const size_t o_aoff = A.add(C.aoff), o_aw = A.add(C.aw), o_s2s = A.add(C.slot2spec), o_ss = A.add(C.spec_slot), o_kU = A.add(kU), o_kN = A.add(kN),
                o_ktoff = A.add(ktwv_off), o_ktn = A.add(ktwv_n), o_vrank = A.add(vrank), o_bnd = A.add(bnd_off), o_gtval = A.add(gtval),
                o_ltval = A.add(ltval), o_gtmask = A.add(gtmask), o_ltmask = A.add(ltmask), o_bmo = A.add(bndmask_off), o_rsoff = A.add(rs_off),
