@@ -287,6 +287,18 @@ class Group:
         self._check(self.dll.kg_group_catalog_upload(self.g, C.addressof(built.desc), generation, hs))
         return hs
 
+    def catalog_build_ec2(self, built, generation=1):
+        """kg_catalog_build_ec2 on every context of the group (each device encodes its own resident copy) -> handle array."""
+        hs = (C.c_void_p * self.n)()
+        self.dll.kg_catalog_build_ec2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+        for i in range(self.n):
+            h = C.c_void_p()
+            st = self.dll.kg_catalog_build_ec2(self.context(i), C.addressof(built.desc), generation, C.byref(h))
+            if st != 0:
+                raise KgError(st, "kg_catalog_build_ec2 on context %d" % i)
+            hs[i] = h
+        return hs
+
     def catalog_update_offerings(self, handles, updates, generation):
         st, a = abi.build_offering_updates(updates)
         self._check(self.dll.kg_group_catalog_update_offerings(self.g, handles, C.addressof(st.desc), a.ctypes.data if len(a) else None, len(a), generation))

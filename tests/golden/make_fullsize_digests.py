@@ -14,12 +14,12 @@ from tests.helpers import c4_full, full_size_problem, records_digest, result_dig
 
 OUT = os.path.join(ROOT, "tests", "golden", "fullsize_digests.json")
 out = json.load(open(OUT)) if os.path.exists(OUT) else {}
-names = sys.argv[1:] or ["c3_full", "c5_full", "c4_full"]
-if "c4_full" in names:
+names = sys.argv[1:] or ["c3_full", "c5_full", "c4_full", "c4_dense_full"]
+for c4name in [n for n in names if n in ("c4_full", "c4_dense_full")]:
     # config 4: every single-node candidate of the 5 000-node cluster + the multi-node prefixes, records and decisions
     from karpenter_amd import abi, workloads as wl
     from oracle import loader
-    types, nodes, bound, order = c4_full()
+    types, nodes, bound, order = c4_full(dense=c4name == "c4_dense_full")
     cat, cl = abi.build_catalog(types), abi.build_cluster(nodes, bound)
     pend, nps = abi.build_pods([]), abi.build_nodepools([wl.default_nodepool()], wl.WELL_KNOWN_LABELS)
     ent = {"n_nodes": len(nodes), "n_bound_pods": len(bound)}
@@ -42,9 +42,11 @@ if "c4_full" in names:
             win = [r for r in recs if int(r["decision"]) != 0]
             ent["single_first_command"] = int(win[0]["candidate"]) if win else -1
     ent["oracle_seconds"] = round(time.time() - t0, 1)
-    out["c4_full"] = ent
-    print("c4_full", ent, flush=True)
-for name in [n for n in names if n != "c4_full"]:
+    out[c4name] = ent
+    print(c4name, ent, flush=True)
+    with open(OUT, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+for name in [n for n in names if n not in ("c4_full", "c4_dense_full")]:
     prob = full_size_problem(name)
     t0 = time.time()
     ro = prob.run_oracle()

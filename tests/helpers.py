@@ -2,7 +2,7 @@
 import functools
 import os
 
-from karpenter_amd import abi, lib, workloads as wl
+from karpenter_amd import abi, lib, problem as _problem, workloads as wl
 from oracle import loader
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,8 +16,7 @@ def catalog776(n_zones=3):
     return zones, types
 
 
-def families(types):
-    return sorted({t["name"].split(".")[0] for t in types})
+families = _problem.families
 
 
 def diff_results(a, b, limit=5):
@@ -56,11 +55,13 @@ def full_size_problem(name):
     raise KeyError(name)
 
 
-def c4_full():
+def c4_full(dense=False):
     """BASELINE.json config 4 at full size: 5 000 existing nodes (seed 11), ~12 bound pods each at ~35 %
-    utilisation, 0 pending pods, 1 NodePool -> (types, nodes, bound, candidate order)."""
+    utilisation, 0 pending pods, 1 NodePool -> (types, nodes, bound, candidate order).  At 35 % every candidate's pods fit
+    elsewhere (5 000 DELETE verdicts); dense=True is the bench's second leg: the same 5 000 nodes filled to 90-100 % of
+    their cpu (seed 17), whose single-node records split into no-op / DELETE / REPLACE about evenly."""
     zones, types = catalog776()
-    nodes, bound = wl.existing_cluster(5000, 11, types, zones)
+    nodes, bound = wl.dense_cluster(5000, 17, types, zones, lo=0.9, hi=1.0) if dense else wl.existing_cluster(5000, 11, types, zones)
     return types, nodes, bound, wl.disruption_order(nodes, bound)
 
 
@@ -86,41 +87,16 @@ def _with_host_ports(pods, seed, every=3):
     return pods
 
 
-class Problem:
+class Problem(_problem.Problem):
     """One scheduling problem in descriptor form, usable by both the oracle and the library."""
-
-    def __init__(self, types, pods, nodepools, nodes=None, bound=None, max_instance_types=60):
-        self.types = types
-        self.raw_pods, self.raw_nodes, self.raw_bound, self.raw_nodepools = pods, nodes, bound, nodepools  # (kept for property checks / variations)
-        self.n_pods = len(pods)
-        self.cat = abi.build_catalog(types)
-        self.pods = abi.build_pods(pods)
-        self.nodepools = abi.build_nodepools(nodepools, wl.WELL_KNOWN_LABELS, max_instance_types)
-        self.cluster = abi.build_cluster(nodes, bound or []) if nodes is not None else None
 
     def run_oracle(self):
         st, rb = loader.solve([self.cat], self.cluster, self.pods, self.nodepools, self.n_pods)
         assert st == 0, "oracle status %d" % st
         return rb
 
-    def run_library(self, L, hcat=None, out=None):
-        own = hcat is None
-        if own:
-            hcat = L.catalog_upload(self.cat)
-        hcl = L.cluster_upload(self.cluster) if self.cluster is not None else None
-        try:
-            return L.solve([hcat], hcl, self.pods, self.nodepools, self.n_pods, out=out)
-        finally:
-            if hcl is not None:
-                L.dll.kg_cluster_free(hcl)
-            if own:
-                L.dll.kg_catalog_free(hcat)
 
-
-def c5_nodepools():
-    """C5: four weighted NodePools {100, 50, 10, 0}, the two heaviest with cpu limits of 2 000 and 10 000 cores."""
-    return [wl.default_nodepool("np-a", weight=100, limits={"cpu": 2000000}), wl.default_nodepool("np-b", weight=50, limits={"cpu": 10000000}),
-            wl.default_nodepool("np-c", weight=10), wl.default_nodepool("np-d", weight=0)]
+c5_nodepools = _problem.c5_nodepools
 
 
 # parity scenarios for the scheduler features beyond the BASELINE shapes (Preferences.Relax steps, minDomains, daemon

@@ -117,14 +117,16 @@ def test_c5_full(L):
     assert result_digest(run(L, prob, False).decode()) == golden["digest"]
 
 
-def test_c4_full(L):
+@pytest.mark.parametrize("name", ["c4_full", "c4_dense_full"])
+def test_c4_full(L, name):
     """BASELINE.json config 4 at its stated size: the 5 000-node cluster, every single-node candidate and the multi-node
     prefixes 2..101, records against the oracle's committed digests (the oracle needs ~5 min for them) and the selected
-    commands; sharded evaluation (3 shards gathered) gives the same records."""
+    commands; sharded evaluation (3 shards gathered) gives the same records.  c4_dense_full: the same nodes at 90-100 %
+    utilisation -- records with no-op, DELETE and REPLACE verdicts (NodeClaims opened, the price filter run)."""
     import numpy as np
     from karpenter_amd import abi
-    golden = json.load(open(GOLDEN))["c4_full"]
-    types, nodes, bound, order = c4_full()
+    golden = json.load(open(GOLDEN))[name]
+    types, nodes, bound, order = c4_full(dense=name == "c4_dense_full")
     assert (len(nodes), len(bound)) == (golden["n_nodes"], golden["n_bound_pods"])
     cat, cl = abi.build_catalog(types), abi.build_cluster(nodes, bound)
     pend, nps = abi.build_pods([]), abi.build_nodepools([wl.default_nodepool()], wl.WELL_KNOWN_LABELS)
