@@ -144,6 +144,13 @@ def test_catalog_build_ec2(L):
     check_ec2_build(L)
 
 
+@pytest.mark.parametrize("check", range(7))
+def test_reference_known_answers(L, check):
+    """The reference's own catalog / scheduling known answers (tests/pins_common.py) through the C ABI."""
+    from tests.pins_common import LibraryBackend, _all_checks
+    _all_checks()[check](LibraryBackend(L))
+
+
 def test_catalog_update_offerings_in_place(L):
     """ICE marks / spot price moves patched into the resident catalog == fresh upload of the rebuilt catalog == oracle."""
     from tests.update_common import check_updates

@@ -182,3 +182,11 @@ def test_min_values_createfleet_requests():
     """cloudprovider/suite_test.go:285-590 on the oracle."""
     from tests.launch_common import OracleBackend, check_min_values_launches
     check_min_values_launches(OracleBackend)
+
+
+@pytest.mark.parametrize("check", range(7))
+def test_reference_known_answers(check):
+    """instancetype/suite_test.go:603-690, 790-851, 1020-1036, 1053-1160, 1165-1525, 1527-1810, 1812-1898, 2186-2279 on the oracle
+    (the same table runs through the C ABI in tests/test_host_logic.py and tests/test_gpu_solve.py)."""
+    from tests.pins_common import OracleBackend, _all_checks
+    _all_checks()[check](OracleBackend)
