@@ -196,6 +196,10 @@ def cons_leg(args, L, hcat, cl, order, multi, world, device, barrier, dist, torc
                         "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": alg,
                         "note": "this rank's simulations of one round: sum over simulations of 212 B x existing nodes visited + 400 B x "
                                 "NodeClaims visited + 336 B x instance types filtered (SURVEY.md 8d) / HIP-event time of k_simulate"}}
+    if achieved > HBM_PEAK_GBS:
+        out["roofline"]["note"] += (" -- above the HBM peak: the count is the REFERENCE algorithm's row visits (a no-op candidate walks every "
+                                    "existing node); the kernel answers most of those visits from the compact prefilter record of a node and reads "
+                                    "the full row only where the prefilter passes, so this figure is work avoided, not bytes moved")
     if cold_steps:
         out["cold"] = {"value": units * cold_steps / cdt, "unit": out["unit"], "ms_per_round": cdt * 1e3 / cold_steps, "rounds": cold_steps,
                        "cluster_upload_ms_rank0": sum(cup) / len(cup),

@@ -2769,6 +2769,17 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   std::vector<uint32_t> rec_of_unit(units.size(), 0);
   for (size_t k = 0; k < mine.size(); ++k) rec_of_unit[mine[k]] = (uint32_t)k;
   const uint8_t* zone_zid = cat->tab.image.bytes.data() + cat->tab.o_zone_zid;
+  struct PriceOrder { uint64_t zmask, ctmask; std::vector<uint32_t> order; };
+  std::vector<PriceOrder> orders;
+  auto price_order = [&](uint64_t zmask, uint64_t ctmask) -> const std::vector<uint32_t>& {
+    for (auto& o : orders) if (o.zmask == zmask && o.ctmask == ctmask) return o.order;
+    orders.push_back({zmask, ctmask, {}});
+    std::vector<uint32_t>& all = orders.back().order;
+    all.resize(cat->types.size());
+    for (uint32_t t = 0; t < all.size(); ++t) all[t] = t;
+    order_by_price(cat, &all, zmask, ctmask);
+    return all;
+  };
   for (size_t li = 0; li < live.size(); ++li) {
     const ConsUnit& un = units[live[li]];
     const SimResult& sr = results[li];
@@ -2788,19 +2799,24 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
       const uint64_t zidm = allowed1(sr.zid_meta, sr.zid_word);
       if (sr.zid_meta & RM_PRESENT)
         for (int z = 0; z < 64; ++z) if (zone_zid[z] != 0xFF && !((zidm >> zone_zid[z]) & 1)) rp.zmask &= ~(1ull << z);
-      for (int w = 0; w < C->TW && w < KG_TWLDS; ++w)
-        for (uint64_t m = sr.mask[w]; m; m &= m - 1) rp.types.push_back((uint32_t)(w * 64 + __builtin_ctzll(m)));
-      order_by_price(cat, &rp.types, rp.zmask, rp.ctmask);
+      // OrderByPrice of the claim's options = the catalog-wide order for these (zone, capacity-type) masks, filtered by the
+      // claim's type mask (a stable sort of a subset keeps the relative order of the stable sort of the whole); a round
+      // sees a handful of distinct mask pairs, so the sort runs that many times instead of once per simulation.  Only
+      // the first max_instance_types of the order are ever looked at.
+      const std::vector<uint32_t>& order = price_order(rp.zmask, rp.ctmask);
+      const size_t limit = nodepools->max_instance_types > 0 ? (size_t)nodepools->max_instance_types : order.size();
+      for (uint32_t t : order) {
+        if (t >= (uint32_t)(std::min(C->TW, (int)KG_TWLDS) * 64) || !((sr.mask[t >> 6] >> (t & 63)) & 1)) continue;
+        rp.types.push_back(t);
+        if (rp.types.size() == limit) break;
+      }
       std::vector<std::pair<uint32_t, int>> mv;
       for (auto& q : C->templates[sr.tmpl].reqs.rs) if (q.min_values >= 0) mv.push_back({q.key, q.min_values});
-      if (nodepools->max_instance_types > 0) {
-        std::vector<uint32_t> trunc(rp.types.begin(), rp.types.begin() + std::min<size_t>(rp.types.size(), (size_t)nodepools->max_instance_types));
-        if (!mv.empty() && !satisfies_min_values(cat, trunc, mv)) {
-          // the claim is dropped and its pods fail: a rescheduled pod among them vetoes the command, otherwise no claim is left
-          rp.types.clear();
-          if (!sr.pad) rp.decision = KG_DECISION_DELETE;
-          priced = false;
-        } else rp.types.swap(trunc);
+      if (nodepools->max_instance_types > 0 && !mv.empty() && !satisfies_min_values(cat, rp.types, mv)) {
+        // the claim is dropped and its pods fail: a rescheduled pod among them vetoes the command, otherwise no claim is left
+        rp.types.clear();
+        if (!sr.pad) rp.decision = KG_DECISION_DELETE;
+        priced = false;
       }
       auto price_filter = [&](double max_price) {  // NodeClaim.RemoveInstanceTypeOptionsByPriceAndMinValues
         remove_by_price(cat, &rp, max_price, spot, od);
