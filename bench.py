@@ -33,7 +33,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "roofline.json")) as _f:
+    ROOFLINE = json.load(_f)   # frozen row sizes + peaks
+HBM_PEAK_GBS = float(ROOFLINE["peak"]["hbm_GBps"])  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
+ROWS_NOTE = "%d B/existing node, %d B/NodeClaim, %d B/instance type (roofline.json)" % (
+    ROOFLINE["row_bytes"]["existing_node"], ROOFLINE["row_bytes"]["node_claim"], ROOFLINE["row_bytes"]["instance_type"])
 PMC_FILE = os.path.join("profiles", "r03_pmc.json")
 
 
@@ -128,8 +132,7 @@ def solve_leg(L, hcat, prob, steps, warmup, barrier=None, want_alg=True):
             "n_claims": int(rb.res.n_claims), "breakdown_ms": {k: sum(v) / steps for k, v in ms.items()},
             "roofline": {"bound": "hbm", "kernel": solve_kernel_name(L, before), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg,
-                         "note": "rows the reference algorithm visits up to its first feasible index (SURVEY.md 8d): "
-                                 "212 B/existing node, 400 B/NodeClaim, 336 B/instance type"}}
+                         "note": "rows the reference algorithm visits up to its first feasible index (SURVEY.md 8d): " + ROWS_NOTE}}
 
 
 def cons_leg(args, L, hcat, cl, order, multi, world, device, barrier, dist, torch, default_workload):
@@ -194,8 +197,8 @@ def cons_leg(args, L, hcat, cl, order, multi, world, device, barrier, dist, torc
            "record_verdicts": {"noop": hist[0], "delete": hist[1], "replace": hist[2]} if hist else None,
            "roofline": {"bound": "hbm", "kernel": "k_simulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": alg,
-                        "note": "this rank's simulations of one round: sum over simulations of 212 B x existing nodes visited + 400 B x "
-                                "NodeClaims visited + 336 B x instance types filtered (SURVEY.md 8d) / HIP-event time of k_simulate"}}
+                        "note": "this rank's simulations of one round: sum over simulations of the rows the reference visits, " + ROWS_NOTE +
+                                " (SURVEY.md 8d) / HIP-event time of k_simulate"}}
     if achieved > HBM_PEAK_GBS:
         out["roofline"]["note"] += (" -- above the HBM peak: the count is the REFERENCE algorithm's row visits (a no-op candidate walks every "
                                     "existing node); the kernel answers most of those visits from the compact prefilter record of a node and reads "

@@ -343,6 +343,13 @@ typedef struct {
 } kg_decision;
 
 /* per-candidate record (also the fixed-size record gathered across GPUs) */
+/* Row sizes of the algorithmic byte count (roofline.json): what one visit of the reference algorithm to an
+ * existing node / an in-flight NodeClaim / an instance type is priced at in kg_results.algorithmic_bytes and
+ * kg_stats.cons_algorithmic_bytes.  They price the REFERENCE's visits, not this library's memory traffic. */
+#define KG_ROW_BYTES_EXISTING_NODE 212
+#define KG_ROW_BYTES_NODE_CLAIM 400
+#define KG_ROW_BYTES_INSTANCE_TYPE 336
+
 #define KG_RECORD_TYPE_WORDS 16
 typedef struct {
   int32_t candidate;         /* index in candidates[] (single) or `mid` = prefix length-1 (multi) */

@@ -1126,7 +1126,11 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
           if (oc == 1 || oc == 3) neg = true; else pos = true;
         }
       if (neg && pos) throw Unsupported("NotIn/DoesNotExist and In/Exists pods on a label some existing node lacks");
-      for (auto& g : groups) if (g.key == C.slot_key[a]) throw Unsupported("topology key missing on an existing node");
+      // A node without the key of a topology group is outside every domain of it: ExistingNode.Add cannot bind the
+      // group's In{domain} to an undefined key (Requirements.Compatible without AllowUndefined), so the node refuses every
+      // pod that consults the group -- what the scan does on the 0xFFFF domain id -- and countDomains skips its pods.
+      // Only a pod that first defines the key on the node through a negative operator escapes that rule upstream.
+      if (neg) for (auto& g : groups) if (g.key == C.slot_key[a]) throw Unsupported("NotIn/DoesNotExist pods on a topology key some existing node lacks");
     }
   }
 
@@ -2210,7 +2214,8 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
   out->visited_claim_types = counters[2];
   out->new_claim_scans = counters[3];
   out->relaxations = header[1];
-  out->algorithmic_bytes = 212.0 * counters[0] + 400.0 * (counters[1] + counters[3]) + 336.0 * counters[2];
+  out->algorithmic_bytes = (double)KG_ROW_BYTES_EXISTING_NODE * counters[0] + (double)KG_ROW_BYTES_NODE_CLAIM * (counters[1] + counters[3]) +
+                           (double)KG_ROW_BYTES_INSTANCE_TYPE * counters[2];
   out->device_ms = ms_pre + ms_solve;
   out->prepass_ms = ms_pre;
   out->solve_ms = ms_solve;
@@ -2726,7 +2731,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
     uint64_t v[4] = {0, 0, 0, 0};
     for (size_t i = 0; i < live.size(); ++i) for (int k = 0; k < 4; ++k) v[k] += results[i].visited[k];
     ctx->stats.cons_simulations = live.size();
-    ctx->stats.cons_algorithmic_bytes = 212.0 * v[0] + 400.0 * (v[1] + v[3]) + 336.0 * v[2];
+    ctx->stats.cons_algorithmic_bytes = (double)KG_ROW_BYTES_EXISTING_NODE * v[0] + (double)KG_ROW_BYTES_NODE_CLAIM * (v[1] + v[3]) + (double)KG_ROW_BYTES_INSTANCE_TYPE * v[2];
     ctx->stats.cons_prepass_ms = ms_pre; ctx->stats.cons_sim_init_ms = ms_init; ctx->stats.cons_simulate_ms = ms_sim; ctx->stats.cons_gather_ms = ms_gather;
     ctx->stats.cons_state_bytes_per_simulation = stride;
   }

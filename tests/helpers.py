@@ -102,7 +102,8 @@ c5_nodepools = _problem.c5_nodepools
 # parity scenarios for the scheduler features beyond the BASELINE shapes (Preferences.Relax steps, minDomains, daemon
 # overhead, node taints / tolerations, capacity-type spread, pod affinity, OR-ed node-affinity terms, negative operators)
 FEATURE_SCENARIOS = ["schedule_anyway", "prefer_no_schedule", "preferred_pod_affinity", "min_domains", "daemon_overhead", "node_taints",
-                     "ct_spread", "pod_affinity", "two_required_terms", "negative_selectors", "relax_everything", "volume_limits"]
+                     "ct_spread", "pod_affinity", "two_required_terms", "negative_selectors", "relax_everything", "volume_limits",
+                     "nodes_without_topology_key"]
 
 
 def _pod(uid, cpu, mem_gi, app, ts=1700000000, **kw):
@@ -278,6 +279,34 @@ def feature_scenario(name):
             elif i % 9 == 2:
                 p["required_terms"] = [[(wl.L_ZONE, "In", ["mars-1a"])], [(G + "/instance-cpu", "In", ["3"])], [(wl.L_ARCH, "In", ["arm64"])]]
         return Problem(types, pods, [wl.default_nodepool()])
+    if name == "nodes_without_topology_key":
+        # a third of the existing nodes carry no zone label (and some no capacity-type label): they are outside every domain
+        # of a zone (capacity-type) topology -- pods that consult such a group cannot land there, their bound pods are not
+        # counted -- while pods without topology still fill them
+        nodes, bound = wl.existing_cluster(45, 23, types, zones, util=0.2)
+        for i, nd in enumerate(nodes):
+            if i % 3 == 0:
+                del nd["labels"][wl.L_ZONE]
+            if i % 5 == 0:
+                del nd["labels"][wl.L_CT]
+        for i, p in enumerate(bound):
+            p["labels"] = {"app": "web-%d" % (i % 3)}
+        pods = []
+        for d in range(3):
+            app = "web-%d" % d
+            sel = {"match_labels": {"app": app}}
+            for k in range(14):
+                kw = {}
+                if d == 0:
+                    kw["spreads"] = [{"key": wl.L_ZONE, "max_skew": 1, "when": "DoNotSchedule", "selector": sel}]
+                elif d == 1:
+                    kw["anti_affinity_required"] = [{"key": wl.L_ZONE, "selector": {"match_labels": {"app": "lonely"}}}]
+                    kw["spreads"] = [{"key": wl.L_CT, "max_skew": 2, "when": "DoNotSchedule", "selector": sel}]
+                else:
+                    kw["affinity_required"] = [{"key": wl.L_ZONE, "selector": sel}]
+                pods.append(_pod("%s-%02d" % (app, k), [250, 500][k % 2], 1, app, ts=1700000000 + d, **kw))
+        pods += [_pod("lonely-%d" % k, 500, 1, "lonely", anti_affinity_required=[{"key": wl.L_ZONE, "selector": {"match_labels": {"app": "lonely"}}}]) for k in range(4)]
+        return Problem(types, pods + wl.mixed_pods(40, 71, zones, fams), [wl.default_nodepool()], nodes=nodes, bound=bound)
     if name == "negative_selectors_wk":
         # the same without the custom label key: negative operators on well-known keys only, which the speculative
         # multi-wave kernel serves (a NodeClaim never lacks a well-known key in the sense of Requirements.Compatible)

@@ -46,3 +46,13 @@ def test_no_cpu_fallback():
     with pytest.raises(lib.KgError) as e:
         lib.Library()
     assert e.value.status == 3  # KG_EDEVICE
+
+
+def test_roofline_row_sizes_are_the_frozen_ones():
+    """roofline.json == the KG_ROW_BYTES_* constants the library prices row visits with."""
+    import json
+    rf = json.load(open(os.path.join(ROOT, "roofline.json")))
+    src = open(HEADER).read()
+    got = {k.lower(): int(v) for k, v in re.findall(r"#define KG_ROW_BYTES_(\w+) (\d+)", src)}
+    assert got == rf["row_bytes"] == {"existing_node": 212, "node_claim": 400, "instance_type": 336}
+    assert rf["peak"]["hbm_GBps"] == 8000.0 and rf["bound"] == "hbm"

@@ -151,6 +151,11 @@ def test_reference_known_answers(L, check):
     _all_checks()[check](LibraryBackend(L))
 
 
+def test_every_refusal_is_reported_and_leaves_the_context_usable(L):
+    from tests.refusal_common import check_refusals
+    assert check_refusals(L) >= 20
+
+
 def test_catalog_update_offerings_in_place(L):
     """ICE marks / spot price moves patched into the resident catalog == fresh upload of the rebuilt catalog == oracle."""
     from tests.update_common import check_updates
@@ -278,3 +283,16 @@ def test_stale_catalog_generation(L):
 def test_volume_limits(L):
     from tests.volume_common import check_volume_limits
     check_volume_limits(L)
+
+
+def test_threaded_abi_on_hip_streams():
+    """tests/native/abi_threads.cpp (four solve threads on one context, consolidation rounds on a second, catalog readers, an
+    in-place catalog writer, a three-context device group -- every result equal to the serial run) linked against the PRODUCT
+    library: real HIP streams and events instead of the emulation HAL the sanitizer builds use."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "_hip", "abi_threads_hip")
+    assert os.path.exists(exe), "tests/native/_hip/abi_threads_hip missing: run __graft_entry__.build()"
+    r = subprocess.run([exe, "3"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=150)
+    out = r.stdout.decode("utf-8", "replace")
+    assert r.returncode == 0 and "abi_threads ok" in out, out[-4000:]

@@ -166,6 +166,11 @@ def test_reference_known_answers(L, check):
     _all_checks()[check](LibraryBackend(L))
 
 
+def test_every_refusal_is_reported_and_leaves_the_context_usable(L):
+    from tests.refusal_common import check_refusals
+    assert check_refusals(L) >= 20
+
+
 def test_catalog_update_offerings_in_place(L):
     """ICE marks / spot price moves patched into the resident catalog == fresh upload of the rebuilt catalog == oracle."""
     from tests.update_common import check_updates
