@@ -58,10 +58,17 @@ std::string PSel::canon() const {
 // ------------------------------------------------------------------ pod parsing (deduplicated by spec signature)
 namespace {
 struct Sig {
-  std::string s;
-  uint64_t h = 0;  // running hash of the words appended so far (the class table is probed with it; the string settles ties)
-  void clear() { s.clear(); h = 0x9E3779B97F4A7C15ull; }
-  void u32(uint32_t v) { s.append((const char*)&v, 4); h = (h ^ v) * 0xFF51AFD7ED558CCDull; h ^= h >> 29; }
+  std::vector<uint32_t> w = std::vector<uint32_t>(256);  // the words appended so far (grown by doubling: no call per word)
+  size_t n = 0;
+  uint64_t h = 0;  // running hash of those words (the class table is probed with it; the words settle ties)
+  void clear() { n = 0; h = 0x9E3779B97F4A7C15ull; }
+  void u32(uint32_t v) {
+    if (n == w.size()) w.resize(n * 2);
+    w[n++] = v;
+    h = (h ^ v) * 0xFF51AFD7ED558CCDull; h ^= h >> 29;
+  }
+  bool same(const std::vector<uint32_t>& o) const { return o.size() == n && memcmp(o.data(), w.data(), n * 4) == 0; }
+  std::vector<uint32_t> words() const { return std::vector<uint32_t>(w.begin(), w.begin() + n); }
   void range_labels(const kg_pools& p, kg_range r) { u32(r.count); for (auto& l : kgdesc::labels(p, r)) { u32(l.key); u32(l.value); } }
   void range_reqs(const kg_pools& p, kg_range r) {
     u32(r.count);
@@ -104,7 +111,7 @@ void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out, bool add_po
   if (!d) return;
   const kg_pools& p = d->pools;
   // pod classes by signature: open addressing on the running hash, the signature bytes compared on a hit
-  std::vector<std::string> class_sig;
+  std::vector<std::vector<uint32_t>> class_sig;
   std::vector<uint64_t> class_hash;
   uint32_t tab_mask = 1023;
   std::vector<uint32_t> tab(tab_mask + 1, UINT32_MAX);
@@ -114,7 +121,6 @@ void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out, bool add_po
   std::vector<int32_t> rid_of_str(p.strings.count, -1);
   std::vector<std::pair<uint32_t, int64_t>> rl;
   Sig sg;
-  sg.s.reserve(1024);
   for (uint32_t i = 0; i < d->n_pods; ++i) {
     const kg_pod& q = d->pods[i];
     sg.clear();
@@ -144,7 +150,7 @@ void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out, bool add_po
     uint32_t slot = (uint32_t)(sg.h >> 20) & tab_mask;
     for (; tab[slot] != UINT32_MAX; slot = (slot + 1) & tab_mask) {
       const uint32_t k = tab[slot];
-      if (class_hash[k] == sg.h && class_sig[k] == sg.s) { cls = k; break; }
+      if (class_hash[k] == sg.h && sg.same(class_sig[k])) { cls = k; break; }
     }
     if (cls == UINT32_MAX) {
       PodClass c;
@@ -172,7 +178,7 @@ void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out, bool add_po
         c.ports.push_back({h.ip == KG_NONE ? -1 : (int)ctx->lab.id(kgdesc::str(p.strings, h.ip)), h.port, (int)h.protocol});
       cls = (uint32_t)out->classes.size();
       out->classes.push_back(std::move(c));
-      class_sig.push_back(sg.s);
+      class_sig.push_back(sg.words());
       class_hash.push_back(sg.h);
       tab[slot] = cls;
       if (class_sig.size() * 2 > tab.size()) {  // keep the table at most half full
@@ -523,6 +529,58 @@ struct HostProf {
   }
 };
 #define KG_PROF(x) prof_.mark(x)
+
+// The Queue's order (byCPUAndMemoryDescending, then creation time, then UID) over `keys`: an LSD radix sort on the three
+// numeric fields -- 16-bit digits, the digits no key differs in skipped (cpu and memory requests are a few round values,
+// creation times of a snapshot lie within days: five or six passes in practice) -- then the runs of full ties ordered by UID.
+// Stable, so equal UIDs keep their input order: the permutation std::stable_sort with the same comparison gives.
+struct QKey { int64_t cpu, mem, creation; uint32_t idx; };
+template <class UidOf>
+static void queue_sort(std::vector<QKey>& keys, UidOf uid_of) {
+  const size_t n = keys.size();
+  if (n < 2) return;
+  if (n < 256) {
+    std::stable_sort(keys.begin(), keys.end(), [&](const QKey& a, const QKey& b) {
+      if (a.cpu != b.cpu) return a.cpu > b.cpu;
+      if (a.mem != b.mem) return a.mem > b.mem;
+      if (a.creation != b.creation) return a.creation < b.creation;
+      return uid_of(a.idx) < uid_of(b.idx);
+    });
+    return;
+  }
+  // ascending sort fields: descending ones complemented, signed ones biased
+  auto f_cre = [](const QKey& k) { return (uint64_t)k.creation ^ (1ull << 63); };
+  auto f_mem = [](const QKey& k) { return ~((uint64_t)k.mem ^ (1ull << 63)); };
+  auto f_cpu = [](const QKey& k) { return ~((uint64_t)k.cpu ^ (1ull << 63)); };
+  std::vector<QKey> tmp(n);
+  std::vector<uint32_t> hist(65536);
+  QKey* src = keys.data();
+  QKey* dst = tmp.data();
+  auto pass_field = [&](auto field) {
+    uint64_t diff = 0;
+    const uint64_t first = field(src[0]);
+    for (size_t i = 1; i < n; ++i) diff |= field(src[i]) ^ first;
+    for (int sh = 0; sh < 64; sh += 16) {
+      if (!((diff >> sh) & 0xFFFF)) continue;
+      std::fill(hist.begin(), hist.end(), 0u);
+      for (size_t i = 0; i < n; ++i) hist[(field(src[i]) >> sh) & 0xFFFF]++;
+      uint32_t run = 0;
+      for (auto& h : hist) { const uint32_t c = h; h = run; run += c; }
+      for (size_t i = 0; i < n; ++i) dst[hist[(field(src[i]) >> sh) & 0xFFFF]++] = src[i];
+      std::swap(src, dst);
+    }
+  };
+  pass_field(f_cre);
+  pass_field(f_mem);
+  pass_field(f_cpu);
+  if (src != keys.data()) memcpy(keys.data(), src, n * sizeof(QKey));
+  for (size_t i = 0; i < n;) {
+    size_t j = i + 1;
+    while (j < n && keys[j].cpu == keys[i].cpu && keys[j].mem == keys[i].mem && keys[j].creation == keys[i].creation) ++j;
+    if (j - i > 1) std::stable_sort(keys.begin() + i, keys.begin() + j, [&](const QKey& a, const QKey& b) { return uid_of(a.idx) < uid_of(b.idx); });
+    i = j;
+  }
+}
 static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool stats) {
   HostProf prof_;
   kg_ctx* ctx = in.ctx;
@@ -993,12 +1051,12 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     pod_variant0[p] = class_variant0[PP.pods[p].cls];
     queue0[p] = (uint32_t)p;
   }
+  KG_PROF("pods: queue order");
   {
     const int rc = ract[ctx->rCPU], rm = ract[ctx->rMemory];
     auto cpu = [&](uint32_t i) { return preq[(size_t)i * R + rc]; };
     auto mem = [&](uint32_t i) { return preq[(size_t)i * R + rm]; };
-    // (keys gathered into one contiguous array first: the comparator then touches 32 bytes per pod instead of three tables)
-    struct QKey { int64_t cpu, mem, creation; uint32_t idx; };
+    // (keys gathered into one contiguous array first: the order then touches 32 bytes per pod instead of three tables)
     auto qless = [&](const QKey& a, const QKey& b) {
       if (a.cpu != b.cpu) return a.cpu > b.cpu;
       if (a.mem != b.mem) return a.mem > b.mem;
@@ -1020,15 +1078,11 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
           for (uint32_t k = pr.rq_off; k < pr.rq_off + pr.rq_n; ++k) { if (cl->bound.rq[k].first == ctx->rCPU) c = cl->bound.rq[k].second; if (cl->bound.rq[k].first == ctx->rMemory) m = cl->bound.rq[k].second; }
           bk[i] = QKey{c, m, pr.creation, (uint32_t)i};
         }
-        std::stable_sort(bk.begin(), bk.end(), [&](const QKey& a, const QKey& b) {
-          if (a.cpu != b.cpu) return a.cpu > b.cpu;
-          if (a.mem != b.mem) return a.mem > b.mem;
-          if (a.creation != b.creation) return a.creation < b.creation;
-          return cl->bound.uid(cl->bound.pods[a.idx]) < cl->bound.uid(cl->bound.pods[b.idx]);
-        });
+        queue_sort(bk, [&](uint32_t i) { return cl->bound.uid(cl->bound.pods[i]); });
         cl->bound_rank.assign(nb, 0);
         for (size_t r = 0; r < nb; ++r) cl->bound_rank[bk[r].idx] = (uint32_t)r;
       }
+      KG_PROF("pods: merge pending into ranked bound");
       std::vector<uint32_t> at_rank(nb, UINT32_MAX);
       std::vector<QKey> pend_keys, bound_keys;
       for (int p = 0; p < P; ++p) {
@@ -1037,12 +1091,15 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
       }
       bound_keys.reserve((size_t)P);
       for (size_t r = 0; r < nb; ++r) if (at_rank[r] != UINT32_MAX) bound_keys.push_back(qkey(at_rank[r]));
-      std::stable_sort(pend_keys.begin(), pend_keys.end(), qless);
-      keys.resize(pend_keys.size() + bound_keys.size());
-      std::merge(pend_keys.begin(), pend_keys.end(), bound_keys.begin(), bound_keys.end(), keys.begin(), qless);
+      queue_sort(pend_keys, [&](uint32_t i) { return PP.uid(PP.pods[i]); });
+      if (pend_keys.empty()) keys.swap(bound_keys);
+      else {
+        keys.resize(pend_keys.size() + bound_keys.size());
+        std::merge(pend_keys.begin(), pend_keys.end(), bound_keys.begin(), bound_keys.end(), keys.begin(), qless);
+      }
     } else {
       for (int p = 0; p < P; ++p) keys.push_back(qkey((uint32_t)p));
-      std::stable_sort(keys.begin(), keys.end(), qless);
+      queue_sort(keys, [&](uint32_t i) { return PP.uid(PP.pods[i]); });
     }
     for (int p = 0; p < P; ++p) queue0[p] = keys[p].idx;
   }
@@ -1812,29 +1869,58 @@ int32_t kg_cluster_upload(kg_ctx* ctx, const kg_cluster_desc* desc, kg_cluster**
   std::unique_ptr<kg_cluster> cl(new kg_cluster());
   KG_GUARD_BEGIN
   cl->ctx = ctx;
+  kg::HostProf prof_;
+  KG_PROF("upload: nodes");
   Vocab& V = ctx->V;
   const kg_pools& p = desc->pods.pools;
+  // A descriptor interns its strings: the label keys, label values and resource names of 5 000 nodes are a few hundred
+  // distinct string ids.  Each is looked up in the vocabulary once; after that a label costs two array reads.
+  const uint32_t NS = p.strings.count;
+  std::vector<uint32_t> key_of(NS, UINT32_MAX), res_of(NS, UINT32_MAX);
+  std::vector<std::pair<uint32_t, uint32_t>> val_of(NS, {UINT32_MAX, 0});  // (key it was resolved under, value id)
+  auto rl = [&](kg_range r) {
+    std::vector<std::pair<uint32_t, int64_t>> out;
+    out.reserve(r.count);
+    for (auto& q : kgdesc::quantities(p, r)) {
+      kgdesc::check(q.name < NS, "string id out of range");
+      uint32_t& rid = res_of[q.name];
+      if (rid == UINT32_MAX) rid = V.resources.id(kgdesc::str(p.strings, q.name));
+      bool merged = false;
+      for (auto& kv : out) if (kv.first == rid) { kv.second += q.milli; merged = true; }
+      if (!merged) out.push_back({rid, q.milli});
+    }
+    std::sort(out.begin(), out.end());  // (ascending resource id, as parse_rl's map gives)
+    return out;
+  };
+  cl->nodes.reserve(desc->n_nodes);
   for (uint32_t i = 0; i < desc->n_nodes; ++i) {
     const kg_node& n = desc->nodes[i];
     CNode cn;
     cn.name = std::string(kgdesc::str(p.strings, n.name));
     bool has_hostname = false;
+    cn.labels.reserve(n.labels.count);
     for (auto& l : kgdesc::labels(p, n.labels)) {
-      uint32_t k = V.key(kgdesc::str(p.strings, l.key));
-      uint32_t v = V.val(k, kgdesc::str(p.strings, l.value));
+      kgdesc::check(l.key < NS && l.value < NS, "string id out of range");
+      uint32_t& k = key_of[l.key];
+      if (k == UINT32_MAX) k = V.key(kgdesc::str(p.strings, l.key));
+      auto& kv = val_of[l.value];
+      if (kv.first != k) kv = {k, V.val(k, kgdesc::str(p.strings, l.value))};
+      const uint32_t v = kv.second;
       cn.labels.push_back({k, v});
       if (k == ctx->kHostname) { has_hostname = true; cn.hostname_val = v; }
     }
     if (!has_hostname) cn.hostname_val = V.val(ctx->kHostname, cn.name);
     for (auto& t : kgdesc::taints(p, n.taints))
       cn.taints.push_back({ctx->lab.id(kgdesc::str(p.strings, t.key)), t.value == KG_NONE ? ctx->lab.id("") : ctx->lab.id(kgdesc::str(p.strings, t.value)), t.effect});
-    cn.available = parse_rl(V, p, n.available);
-    cn.capacity = parse_rl(V, p, n.capacity);
-    cn.daemon = parse_rl(V, p, n.daemon_requests);
+    cn.available = rl(n.available);
+    cn.capacity = rl(n.capacity);
+    cn.daemon = rl(n.daemon_requests);
     cn.initialized = n.initialized; cn.managed = n.managed; cn.deleting = n.deleting;
     cl->nodes.push_back(std::move(cn));
   }
+  KG_PROF("upload: bound pods");
   parse_pods(ctx, &desc->pods, &cl->bound, true);
+  KG_PROF("upload: volume limits");
   for (auto& bp : cl->bound.pods) check(bp.node >= 0 && bp.node < (int)cl->nodes.size(), "bound pod node index");
   // volume limits: what the node can still attach per CSI driver = CSINode count - volumes of the pods bound to it (clamped at
   // 0: a node over its limit takes no more volumes but still takes pods without any)
@@ -1850,6 +1936,7 @@ int32_t kg_cluster_upload(kg_ctx* ctx, const kg_cluster_desc* desc, kg_cluster**
       cl->nodes[i].volume_limited.push_back(rid);
     }
   }
+  KG_PROF("upload: end");
   *out = cl.release();
   return KG_OK;
   KG_GUARD_END(ctx)
@@ -2372,21 +2459,40 @@ static std::unique_ptr<kg_cons_plan> build_cons_plan(kg_ctx* ctx, kg_catalog* ca
   U.classes.insert(U.classes.end(), cluster->bound.classes.begin(), cluster->bound.classes.end());
   std::vector<uint8_t> nonpending;
   std::vector<int32_t> universe_bound;
+  // the bound pods keep their request pairs and UIDs where the cluster snapshot holds them: both pools are appended whole
+  // behind the pending pods' and a bound pod's offsets move by the pending pools' sizes (no copy per pod)
+  const uint32_t rq_shift = (uint32_t)pend.rq.size(), uid_shift = (uint32_t)pend.uid_pool.size();
+  U.rq.reserve(pend.rq.size() + cluster->bound.rq.size());
   U.rq = pend.rq;
-  U.pods.reserve(pend.pods.size() + cluster->bound.pods.size());
+  U.rq.insert(U.rq.end(), cluster->bound.rq.begin(), cluster->bound.rq.end());
+  U.uid_pool.reserve(pend.uid_pool.size() + cluster->bound.uid_pool.size());
+  U.uid_pool = pend.uid_pool;
+  U.uid_pool += cluster->bound.uid_pool;
+  const size_t n_bound = cluster->bound.pods.size();
+  U.pods.reserve(pend.pods.size() + n_bound);
+  nonpending.reserve(pend.pods.size() + n_bound);
+  universe_bound.reserve(pend.pods.size() + n_bound);
   for (auto& p : pend.pods) { U.pods.push_back(p); nonpending.push_back(0); universe_bound.push_back(-1); }
-  std::vector<std::vector<uint32_t>> pods_of_node(cluster->nodes.size());
-  for (size_t i = 0; i < cluster->bound.pods.size(); ++i)
-    if (cluster->bound.pods[i].reschedulable) pods_of_node[cluster->bound.pods[i].node].push_back((uint32_t)i);
-  auto add_bound = [&](uint32_t bi) {
-    PodRef pr = cluster->bound.pods[bi];
-    pr.cls += cls_off;
-    const uint32_t o = pr.rq_off;
-    pr.rq_off = (uint32_t)U.rq.size();
-    U.rq.insert(U.rq.end(), cluster->bound.rq.begin() + o, cluster->bound.rq.begin() + o + pr.rq_n);
-    U.pods.push_back(std::move(pr));
-    nonpending.push_back(1);
-    universe_bound.push_back((int32_t)bi);
+  // reschedulable bound pods by node (counting sort: descriptor order within a node)
+  std::vector<uint32_t> node_begin(cluster->nodes.size() + 1, 0), node_pods;
+  for (size_t i = 0; i < n_bound; ++i) if (cluster->bound.pods[i].reschedulable) node_begin[cluster->bound.pods[i].node + 1]++;
+  for (size_t nd = 0; nd < cluster->nodes.size(); ++nd) node_begin[nd + 1] += node_begin[nd];
+  node_pods.resize(node_begin[cluster->nodes.size()]);
+  {
+    std::vector<uint32_t> fill(node_begin.begin(), node_begin.end() - 1);
+    for (size_t i = 0; i < n_bound; ++i) if (cluster->bound.pods[i].reschedulable) node_pods[fill[cluster->bound.pods[i].node]++] = (uint32_t)i;
+  }
+  auto add_node = [&](size_t nd) {
+    for (uint32_t k = node_begin[nd]; k < node_begin[nd + 1]; ++k) {
+      const uint32_t bi = node_pods[k];
+      PodRef pr = cluster->bound.pods[bi];
+      pr.cls += cls_off;
+      pr.rq_off += rq_shift;
+      pr.uid_off += uid_shift;
+      U.pods.push_back(pr);
+      nonpending.push_back(1);
+      universe_bound.push_back((int32_t)bi);
+    }
   };
   std::vector<uint8_t> is_cand(cluster->nodes.size(), 0);
   // multi: firstNConsolidationOption gets max = Clamp(len, 0, 100) and only lowers it to len - 1 when len <= max, so with more than
@@ -2396,14 +2502,14 @@ static std::unique_ptr<kg_cons_plan> build_cons_plan(kg_ctx* ctx, kg_catalog* ca
   PL.candidates.assign(cands->candidates, cands->candidates + n_used);
   for (uint32_t i = 0; i < n_used; ++i) is_cand[cands->candidates[i]] = 1;
   for (size_t nd = 0; nd < cluster->nodes.size(); ++nd)
-    if (cluster->nodes[nd].deleting && !is_cand[nd]) for (uint32_t bi : pods_of_node[nd]) add_bound(bi);
+    if (cluster->nodes[nd].deleting && !is_cand[nd]) add_node(nd);
   const uint32_t n_shared = (uint32_t)U.pods.size();
   PL.n_shared = n_shared;
   std::vector<uint32_t>& cand_begin = PL.cand_begin;
   cand_begin.assign(n_used + 1, n_shared);
   for (uint32_t i = 0; i < n_used; ++i) {
     cand_begin[i] = (uint32_t)U.pods.size();
-    for (uint32_t bi : pods_of_node[cands->candidates[i]]) add_bound(bi);
+    add_node((size_t)cands->candidates[i]);
   }
   cand_begin[n_used] = (uint32_t)U.pods.size();
 

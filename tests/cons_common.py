@@ -18,6 +18,16 @@ def cluster(name, n):
     if name == "dense_pending":
         nodes, bound = wl.dense_cluster(n, 5, types, zones, lo=0.8, hi=0.99)
         return types, nodes, bound, wl.mixed_pods(6, 9, zones, families(types))
+    if name == "pending_ties":
+        # pending pods that tie with bound pods (and with each other) on cpu, memory and creation time: the Queue order among
+        # them is the UID's, across the pending / bound boundary of the simulations' pod universe
+        nodes, bound = wl.dense_cluster(n, 13, types, zones, lo=0.6, hi=0.99)
+        pending = []
+        for k, p in enumerate(bound[::max(1, len(bound) // 12)][:12]):
+            for tag in ("a", "zz"):   # one UID before every "node-..." UID, one after
+                pending.append({"uid": "%s-tie-%02d" % (tag, k), "ns": "default", "creation_ts": p["creation_ts"], "labels": {"app": "tie"},
+                                "requests": dict(p["requests"])})
+        return types, nodes, bound, pending
     if name == "uninitialized":
         nodes, bound = wl.dense_cluster(n, 3, types, zones, lo=0.5, hi=0.9)
         for i, nd in enumerate(nodes):

@@ -18,7 +18,7 @@ def L():
 
 
 @pytest.mark.parametrize("name,n,s2s", [("dense", 120, False), ("dense", 120, True), ("sparse", 60, False), ("dense_pending", 80, True),
-                                         ("uninitialized", 60, False), ("topology", 80, True), ("host_ports", 80, False), ("minvalues_tight", 80, True), ("minvalues_trunc_pending", 60, False), ("volumes", 90, True)])
+                                         ("uninitialized", 60, False), ("topology", 80, True), ("host_ports", 80, False), ("minvalues_tight", 80, True), ("minvalues_trunc_pending", 60, False), ("volumes", 90, True), ("pending_ties", 70, False)])
 def test_consolidation(L, name, n, s2s):
     seen = check_consolidation(L, name, n, s2s)
     if name == "dense":

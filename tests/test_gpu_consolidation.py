@@ -16,7 +16,7 @@ def L():
 
 
 @pytest.mark.parametrize("name,n,s2s", [("dense", 150, False), ("dense", 150, True), ("sparse", 100, False), ("dense_pending", 120, True),
-                                         ("uninitialized", 90, False), ("dense", 400, True), ("topology", 150, True), ("topology", 400, False), ("host_ports", 150, False), ("minvalues_loose", 120, True), ("minvalues_tight", 150, False), ("minvalues_trunc_pending", 120, True), ("volumes", 150, True)])
+                                         ("uninitialized", 90, False), ("dense", 400, True), ("topology", 150, True), ("topology", 400, False), ("host_ports", 150, False), ("minvalues_loose", 120, True), ("minvalues_tight", 150, False), ("minvalues_trunc_pending", 120, True), ("volumes", 150, True), ("pending_ties", 120, False)])
 def test_consolidation(L, name, n, s2s):
     check_consolidation(L, name, n, s2s)
 
