@@ -264,7 +264,8 @@ static_assert(sizeof(PodCtx) % 8 == 0, "PodCtx is copied as 64-bit words");
 static_assert(sizeof(PodCtx) <= 4 * 64 * 8, "the single-wave kernel prefetches a pod context as four 8-byte words per lane");
 
 struct SharedBase {
-  uint32_t best2[2], reason, pad0_;  // first feasible existing node (slot = placement parity); reasons of the pod being placed
+  uint32_t best2[2], reason, pf_topo;  // first feasible existing node (slot = placement parity); reasons of the pod being placed;
+                                     // pf_topo: the prefilter turned a NodeClaim away for a topology group (-> reason bit 4)
   uint32_t thr_lds, tw_lds, off_lds, stw_lds;
   uint32_t fresh_lim[2];            // per template attempt (alternating): some instance type is within the limits
   uint32_t feas[2], mvf[2];         // per pass (alternating): rows whose option mask stays non-empty / rows failing minValues
@@ -272,6 +273,7 @@ struct SharedBase {
   uint32_t thr_stride0;             // first stride of the 8-ary fit-threshold search: 8^k with 8^(k+1) >= the longest threshold list
   uint32_t ffeas[4];                // wave-local evaluation (fast path): feasible rows of pass k in slot k & 3, slot (k + 1) & 3 cleared meanwhile
   unsigned long long ball[16];      // prefilter ballots of the current chunk of scan positions, one word per wave
+  unsigned long long tallow[KG_MAXLIST];  // per topology entry of the pod being placed: domains that could still take it (topo_allow)
   uint16_t wpos[16][KG_MAXGP];      // chunk positions of each wave's first survivors, in order
   uint4 qn[2];                      // the queue entry two behind the head, staged while a pod is placed (slot = placement parity)
   PodCtx pcb[2];                    // the pod being placed / the next pod of the queue, fetched while the current one is placed
@@ -437,6 +439,40 @@ KG_HD bool topo_host(const SimState& S, const DevProblem& P, const Group& g, boo
   if (g.type == TG_SPREAD) return (int64_t)c + (self ? 1 : 0) <= g.max_skew;  // min is 0 for hostname
   if (g.type == TG_AFFINITY) return c > 0 || (self && S.hpos[g.hidx] == 0);
   return c == 0;
+}
+
+// The domains of a <= 64-domain group that could still take the pod, whatever NodeClaim it goes to: a NodeClaim whose
+// requirement on the key is a plain value set disjoint from this mask fails topo_small + the merge that follows it
+// (row_topology), because both only narrow the set.  ~0 = nothing can be said here (hostname groups, an affinity group
+// that would bootstrap).  The prefilter of the NodeClaim scan tests it; the exact evaluation stays the judge.
+KG_HD uint64_t topo_allow(const DevProblem& P, const SimState& S, const Group& g, const ListEntry& le) {
+  if (g.spec == 0xFF) return ~0ull;
+  const uint32_t gi = le.g;
+  const bool self = le.flags & LF_SELF;
+  const uint64_t podDom = ((uint64_t)le.poddom_hi << 32) | le.poddom_lo;
+  const uint64_t gd = S.gdom[gi];
+  if (g.type == TG_SPREAD) {
+    const auto* cnt = S.gcount + (size_t)gi * 64;
+    int32_t mn = 0x7FFFFFFF;
+    int supported = 0;
+    for (uint64_t m = gd & podDom; m; m &= m - 1) {
+      const int d = ctz64(m);
+      supported++;
+      if (cnt[d] < mn) mn = cnt[d];
+    }
+    if (g.min_domains >= 0 && supported < g.min_domains) mn = 0;
+    uint64_t al = 0;
+    for (uint64_t m = gd; m; m &= m - 1) {
+      const int d = ctz64(m);
+      if ((int64_t)cnt[d] + (self ? 1 : 0) - mn <= g.max_skew) al |= 1ull << d;
+    }
+    return al;
+  }
+  if (g.type == TG_AFFINITY) {
+    const uint64_t opts = gd & podDom & S.gpos[gi];
+    return opts ? opts : ~0ull;
+  }
+  return gd & ~S.gpos[gi] & podDom;
 }
 
 KG_HD void record_small(const SimState& S, uint32_t gi, int d) {
@@ -1399,7 +1435,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     const PodCtx& pc = sh.pcb[cur];
     PodCtx& nx = sh.pcb[cur ^ 1];
     const uint32_t bslot = placement & 1;   // sh.best2 slot of this placement; the other one is reset meanwhile
-    KG_FOR_THREADS(tid, NT) { if (tid == 0) sh.reason = 0; }  // (only thread 0 ever touches it)
+    KG_FOR_THREADS(tid, NT) { if (tid == 0) { sh.reason = 0; sh.pf_topo = 0; } }  // (only thread 0 ever touches sh.reason)
     // the entry behind the head is settled (a push lands behind it) when at least one pod is left
     // ... and so is the one behind that when two are left: it is requested together with the other loads of this
     // placement and parked in LDS, so the next placement's context fetch does not wait for the queue first (and no load
@@ -1475,6 +1511,14 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     // describes), so stage 0 walks the order in chunks of NT positions: a conservative prefilter (thread per position,
     // ballot = survivors in order) -> exact NodeClaim.Add on the survivors, GP at a time, and the first claim that
     // accepts the pod ends the scan.  Stage 1 runs the same NodeClaim.Add on one freshly materialised claim per template.
+    // Topology in the prefilter: a pod with topology groups passes almost every claim on resources and options alone and
+    // then fails NodeClaim.Add on most of them (a hostname spread leaves one replica per claim; a zone spread rules out the
+    // claims already pinned to a full zone).  What can be decided per claim from one or two words is decided there.
+    const bool topo_pf = !STATS && KG_UNI(pc.vc.nlist) != 0;
+    if (topo_pf) {
+      KG_FOR_THREADS(tid, NT) { if ((uint32_t)tid < pc.vc.nlist) sh.tallow[tid] = topo_allow(P, S, pc.vc.lst[tid].g, pc.vc.lst[tid].le); }
+      KG_SYNCW(0);
+    }
     last_c = KG_NOIDX; last_new = 0;
     uint32_t stage = 0, tnext = 0, base = 0, result = 0, win_g = 0;
     fast_win = false;
@@ -1519,10 +1563,24 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
                 const uint64_t* pm = P.podmask + (size_t)variant * P.TW;
                 for (int w = 0; w < P.TW; ++w) any |= S.c_mask[(size_t)w * P.Cmax + c] & pm[w];
               }
+              bool tok = true;
+              if (topo_pf) {
+                for (uint32_t li = 0; li < pc.vc.nlist; ++li) {   // (uniform trip count and branches: the loads join the round trip above)
+                  const Group g = pc.vc.lst[li].g;
+                  if (g.spec == 0xFF) { tok = tok && topo_host(S, P, g, pc.vc.lst[li].le.flags & LF_SELF, (uint32_t)P.N + c); continue; }
+                  const uint64_t al = sh.tallow[li];
+                  const int a = sh.spec_slot[g.spec];
+                  const uint32_t cm = S.c_meta[(size_t)a * P.Cmax + c];
+                  const uint64_t cw = S.c_bits[(size_t)sh.aoff[a] * P.Cmax + c];
+                  if ((cm & RM_PRESENT) && !(cm & RM_COMPL) && !(cw & al)) tok = false;
+                }
+              }
               ok = ((pc.tolw >> tm) & 1) && pc.vc.v.host_claim_ok && any != 0;
               if (P.has_ports) ok = ok && !(S.c_ports[c] & pc.vc.hp_conf);
 #pragma unroll
               for (int r = 0; r < KG_MAXR; ++r) ok = ok && (!((need >> r) & 1) || hd[r] >= pc.preq[r]);
+              if (ok && !tok) sh.pf_topo = 1;  // (same value from every thread)
+              ok = ok && tok;
             }
           }
           KG_ST(1);
@@ -1900,7 +1958,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
       if (tid == 0) {
         S.pod_kind[pod_row(S, pod)] = 0;
         S.pod_index[pod_row(S, pod)] = -1;
-        S.pod_reason[pod_row(S, pod)] = sh.reason ? sh.reason : 8;
+        S.pod_reason[pod_row(S, pod)] = (sh.reason | (sh.pf_topo ? 4u : 0u)) ? (sh.reason | (sh.pf_topo ? 4u : 0u)) : 8;
         uint4 qn;
         qn.x = pod;
         if (vnext >= 0) {
