@@ -1032,6 +1032,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
       v.record_off = rec_off; v.record_cnt = (uint32_t)rec.size();
       v.next = next;
       v.host_claim_ok = rs_host_claim_ok[vt.rs];
+      v.pm_all = reqsets[vt.rs].rs.empty() ? 1u : 0u;
       next = (int32_t)variants.size();
       variants.push_back(v);
       variant_class.push_back((uint32_t)ci);

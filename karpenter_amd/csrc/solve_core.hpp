@@ -71,7 +71,7 @@ struct Variant {
   uint32_t record_off, record_cnt;  // topology groups updated by Record
   int32_t next;       // variant after one Preferences.Relax step, -1 if none
   uint32_t host_claim_ok;  // pod's hostname requirement admits a fresh placeholder hostname
-  uint32_t pad;
+  uint32_t pm_all;         // the pod's requirement set is empty: it rules out no instance type (its option mask is all ones)
 };
 
 struct ListEntry {
@@ -1514,6 +1514,9 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     // Topology in the prefilter: a pod with topology groups passes almost every claim on resources and options alone and
     // then fails NodeClaim.Add on most of them (a hostname spread leaves one replica per claim; a zone spread rules out the
     // claims already pinned to a full zone).  What can be decided per claim from one or two words is decided there.
+    // a pod whose own requirements rule out no instance type (no selector, no affinity terms: every replica of a plain
+    // deployment) intersects every claim's options -- a claim always has some -- so the prefilter leaves the option words alone
+    const bool pm_all = KG_UNI(pc.vc.v.pm_all) != 0;
     const bool topo_pf = !STATS && KG_UNI(pc.vc.nlist) != 0;
     if (topo_pf) {
       KG_FOR_THREADS(tid, NT) { if ((uint32_t)tid < pc.vc.nlist) sh.tallow[tid] = topo_allow(P, S, pc.vc.lst[tid].g, pc.vc.lst[tid].le); }
@@ -1551,7 +1554,8 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
 #pragma unroll
               for (int r = 0; r < KG_MAXR; ++r) if ((need >> r) & 1) hd[r] = S.c_head[(size_t)r * P.Cmax + c];
               uint64_t any = 0;
-              if (P.TW <= KG_TWLDS) {
+              if (pm_all) any = 1;
+              else if (P.TW <= KG_TWLDS) {
                 uint64_t mk[KG_TWLDS];
 #pragma unroll
                 for (int w = 0; w < KG_TWLDS; ++w) mk[w] = 0;
