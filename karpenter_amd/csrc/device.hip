@@ -1,4 +1,4 @@
-// device.hip -- gfx950 kernels and the HIP implementation of hal.hpp.
+// device.hip -- the small gfx950 kernels and the HIP implementation of hal.hpp (the solve kernels: dev_part.hip).
 #include <hip/hip_runtime.h>
 #include <rocprofiler-sdk-roctx/roctx.h>
 
@@ -8,7 +8,7 @@
 #include <vector>
 
 #include "hal.hpp"
-#include "solve_spec.hpp"
+#include "dev_kernels.hpp"
 
 namespace kg {
 
@@ -46,69 +46,6 @@ __global__ void __launch_bounds__(256) k_pod_ctx(DevProblem P, PrepassTables X) 
   const uint32_t per = sizeof(PodCtx) / 8;
   if (i >= (uint32_t)P.NV * per || P.TW > KG_TWLDS) return;
   ((uint64_t*)X.pctx_out)[i] = pod_ctx_word(P, i / per, i % per);
-}
-
-// k_solve: one workgroup = one Scheduler.Solve (persistent over the whole pod queue)
-template <int NT, bool DBG>
-__global__ void __launch_bounds__(NT) k_solve(DevProblem Pin, const SimState* sims, const uint32_t* nqueue) {
-  __shared__ Shared sh;
-  const DevProblem& P = Pin;
-  const SimState S = sims[blockIdx.x];
-  const unsigned long long c0 = clock64(), w0 = wall_clock64();
-  solve_block<NT, DBG>(P, S, sh, nqueue[blockIdx.x]);
-  if (DBG && (P.stats & 2) && threadIdx.x == 0) { S.counters[24] = clock64() - c0; S.counters[25] = wall_clock64() - w0; }
-}
-
-// k_simulate: the same solve loop, one workgroup per consolidation simulation (a kernel of its own so that profiles keep
-// the one persistent Solve and the batches of simulations apart)
-// Its LDS is dynamic: a simulation rarely opens NodeClaims, so it gets sim_gp_cap(NT) evaluation groups instead of
-// KG_MAXGP (DevProblem::gp_cap tells solve_block), 52 KB instead of 74, and THREE 256-thread workgroups share a CU; the
-// second launch bound is the register budget that goes with it (168 per thread).  Simulations do not contend with each
-// other (tools/gpu_sim_sweep.py): each is one chain of dependent placements, so residency is throughput.
-constexpr uint32_t sim_gp_cap(int nt) { return (uint32_t)(nt / 64 > KG_GPMIN ? nt / 64 : KG_GPMIN); }
-constexpr size_t sim_lds_bytes(int nt) { return sizeof(Shared) - (size_t)(KG_MAXGP - sim_gp_cap(nt)) * sizeof(Row); }
-static_assert(sim_lds_bytes(256) * 3 <= 160 * 1024, "three workgroups of k_simulate share a CU's 160 KB of LDS");
-static_assert(sim_lds_bytes(512) <= 64 * 1024, "dynamic LDS without an opt-in attribute");
-extern __shared__ __align__(16) unsigned char sim_lds[];
-// OCC: workgroups per CU the register budget allows.  3 (168 registers, a few dozen spilled) for a batch that fills the
-// chip more than twice over; 2 (256 registers, none spilled) for a small batch, whose time is its longest simulation.
-template <int NT, bool DBG, int OCC>
-__global__ void __launch_bounds__(NT, OCC) k_simulate(DevProblem Pin, const SimState* sims, const uint32_t* nqueue) {
-  Shared& sh = *reinterpret_cast<Shared*>(sim_lds);
-  const DevProblem& P = Pin;
-  const SimState S = sims[blockIdx.x];
-  solve_block<NT, DBG>(P, S, sh, nqueue[blockIdx.x]);
-}
-// k_solve_wave: one WAVE = one Scheduler.Solve (solve_wave.hpp: batches without topology groups / existing nodes / minValues)
-template <bool DBG>
-__global__ void __launch_bounds__(64) k_solve_wave(DevProblem Pin, const SimState* sims, const uint32_t* nqueue) {
-  __shared__ SharedBase sh;
-  __shared__ __attribute__((aligned(16))) uint64_t pool[KG_POOL_WORDS];  // fit-threshold rows + prefilter records: the rest of the CU's 160 KiB
-  static_assert(sizeof(SharedBase) + sizeof(uint64_t) * KG_POOL_WORDS <= 160 * 1024, "LDS of one CU");
-  const DevProblem& P = Pin;
-  const SimState S = sims[blockIdx.x];
-  // the same two descriptors in memory, for the rare paths (solve_wave.hpp: rare_view): Pin is the first kernel argument, so
-  // the kernel-argument segment starts with it; the state descriptors are written by the host before the launch and never
-  // by a kernel
-  const KG_CONST DevProblem* Pk = (const KG_CONST DevProblem*)__builtin_amdgcn_kernarg_segment_ptr();
-  const KG_CONST SimState* Sk = (const KG_CONST SimState*)(sims + blockIdx.x);
-  solve_wave<DBG>(P, S, Pk, Sk, sh, pool, nqueue[blockIdx.x]);
-}
-
-// k_solve_spec: W waves of one workgroup = one Scheduler.Solve, W pods in flight (solve_spec.hpp: same batches as k_solve_wave,
-// minus those with negative operators on custom label keys)
-constexpr uint32_t KG_SPEC_POOL_WORDS = (160 * 1024 - (uint32_t)sizeof(SharedBase) - (uint32_t)sizeof(SpecCtl)) / 8 - 4;
-template <int W, bool DBG>
-__global__ void __launch_bounds__(64 * W) k_solve_spec(DevProblem Pin, const SimState* sims, const uint32_t* nqueue) {
-  __shared__ SharedBase sh;
-  __shared__ SpecCtl ctl;
-  __shared__ __attribute__((aligned(16))) uint64_t pool[KG_SPEC_POOL_WORDS];
-  static_assert(sizeof(SharedBase) + sizeof(SpecCtl) + sizeof(uint64_t) * KG_SPEC_POOL_WORDS <= 160 * 1024, "LDS of one CU");
-  const DevProblem& P = Pin;
-  const SimState S = sims[blockIdx.x];
-  const KG_CONST DevProblem* Pk = (const KG_CONST DevProblem*)__builtin_amdgcn_kernarg_segment_ptr();
-  const KG_CONST SimState* Sk = (const KG_CONST SimState*)(sims + blockIdx.x);
-  solve_spec<W, DBG>(P, S, Pk, Sk, sh, ctl, pool, KG_SPEC_POOL_WORDS, nqueue[blockIdx.x]);
 }
 
 // k_price_order_truncate: one workgroup per new NodeClaim (solve_core.hpp: InstanceTypes.OrderByPrice / Truncate)
@@ -335,15 +272,6 @@ struct Timer {
   }
 };
 
-template <int NT, bool DBG>
-static void launch_k_simulate(DevProblem P, const SimState* sims, int nsims, const uint32_t* nqueue) {
-  P.gp_cap = sim_gp_cap(NT);
-  if (NT == 256 && !DBG && nsims > 2 * 256)  // (256 CUs: more simulations than two per CU)
-    hipLaunchKernelGGL((k_simulate<NT, DBG, (NT == 256 && !DBG) ? 3 : 1>), dim3(nsims), dim3(NT), sim_lds_bytes(NT), t_stream, P, sims, nqueue);
-  else
-    hipLaunchKernelGGL((k_simulate<NT, DBG, (NT == 256 && !DBG) ? 2 : 1>), dim3(nsims), dim3(NT), sim_lds_bytes(NT), t_stream, P, sims, nqueue);
-}
-
 void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms) {
   Timer t("kg prepass (k_type_filter, k_node_static, k_pod_mask, k_pod_ctx)");
   const uint32_t total = X.E * (uint32_t)P.TW;
@@ -360,37 +288,25 @@ void launch_prepass(const DevProblem& P, const PrepassTables& X, float* ms) {
 void launch_solve(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int block, float* ms, bool batch) {
   Timer t("kg solve (k_solve / k_simulate)");
   if (batch) {
-    if (block >= 512) launch_k_simulate<512, false>(P, sims, nsims, nqueue);
-    else launch_k_simulate<256, false>(P, sims, nsims, nqueue);
+    enqueue_k_simulate(P, sims, nsims, nqueue, block, false, t_stream);
     ck(hipGetLastError(), "simulate launch");
     *ms = t.stop();
     return;
   }
   if (P.stats & 2) launch_probes(P, sims, t_stream);  // (debug_probes.hip)
-  if (P.stats & (2 | 8)) hipLaunchKernelGGL((k_solve<256, true>), dim3(nsims), dim3(256), 0, t_stream, P, sims, nqueue);  // debug timers: 256 threads only
-  else if (block >= 1024) hipLaunchKernelGGL((k_solve<1024, false>), dim3(nsims), dim3(1024), 0, t_stream, P, sims, nqueue);
-  else if (block >= 512) hipLaunchKernelGGL((k_solve<512, false>), dim3(nsims), dim3(512), 0, t_stream, P, sims, nqueue);
-  else hipLaunchKernelGGL((k_solve<256, false>), dim3(nsims), dim3(256), 0, t_stream, P, sims, nqueue);
+  enqueue_k_solve(P, sims, nsims, nqueue, block, (P.stats & (2 | 8)) != 0, t_stream);  // (debug timers: 256 threads only)
   ck(hipGetLastError(), "solve launch");
   *ms = t.stop();
 }
 void launch_solve_wave(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, float* ms) {
   Timer t("kg solve (k_solve_wave)");
-  if (P.stats & 8) hipLaunchKernelGGL((k_solve_wave<true>), dim3(nsims), dim3(64), 0, t_stream, P, sims, nqueue);
-  else hipLaunchKernelGGL((k_solve_wave<false>), dim3(nsims), dim3(64), 0, t_stream, P, sims, nqueue);
+  enqueue_k_solve_wave(P, sims, nsims, nqueue, (P.stats & 8) != 0, t_stream);
   ck(hipGetLastError(), "solve (wave) launch");
   *ms = t.stop();
 }
 void launch_solve_spec(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int waves, float* ms) {
   Timer t("kg solve (k_solve_spec)");
-  if (P.stats & 8) {  // (debug: per-wave cycle accounting)
-    if (waves >= 8) hipLaunchKernelGGL((k_solve_spec<8, true>), dim3(nsims), dim3(512), 0, t_stream, P, sims, nqueue);
-    else hipLaunchKernelGGL((k_solve_spec<4, true>), dim3(nsims), dim3(256), 0, t_stream, P, sims, nqueue);
-  }
-  else if (waves >= 8) hipLaunchKernelGGL((k_solve_spec<8, false>), dim3(nsims), dim3(512), 0, t_stream, P, sims, nqueue);
-  else if (waves >= 6) hipLaunchKernelGGL((k_solve_spec<6, false>), dim3(nsims), dim3(384), 0, t_stream, P, sims, nqueue);
-  else if (waves >= 4) hipLaunchKernelGGL((k_solve_spec<4, false>), dim3(nsims), dim3(256), 0, t_stream, P, sims, nqueue);
-  else hipLaunchKernelGGL((k_solve_spec<2, false>), dim3(nsims), dim3(128), 0, t_stream, P, sims, nqueue);
+  enqueue_k_solve_spec(P, sims, nsims, nqueue, waves, (P.stats & 8) != 0, t_stream);  // (debug: per-wave cycle accounting)
   ck(hipGetLastError(), "solve (speculative) launch");
   *ms = t.stop();
 }
@@ -421,9 +337,7 @@ void launch_sim_round(const DevProblem& P, const SimBatch& B, const SimState* si
   ck(hipEventRecord(ev[0], t_stream), "record");
   hipLaunchKernelGGL(k_sim_init, dim3(B.nsims), dim3(256), 0, t_stream, P, B);
   ck(hipEventRecord(ev[1], t_stream), "record");
-  if (P.stats & 8) launch_k_simulate<256, true>(P, sims, B.nsims, B.nqueue);  // (debug: per-wave cycle accounting)
-  else if (block >= 512) launch_k_simulate<512, false>(P, sims, B.nsims, B.nqueue);
-  else launch_k_simulate<256, false>(P, sims, B.nsims, B.nqueue);
+  enqueue_k_simulate(P, sims, B.nsims, B.nqueue, block, (P.stats & 8) != 0, t_stream);  // (debug: per-wave cycle accounting)
   ck(hipEventRecord(ev[2], t_stream), "record");
   hipLaunchKernelGGL(k_sim_gather, dim3(B.nsims), dim3(64), 0, t_stream, P, B, sims);
   ck(hipEventRecord(ev[3], t_stream), "record");

@@ -2136,6 +2136,14 @@ static int32_t solve_impl(kg_ctx* ctx, kg_catalog* const* catalogs, kg_cluster* 
         for (int w = 0; w < nw; ++w) { fprintf(stderr, " %9.0f", counters[64 + 16 * w + k] / (k == 9 ? 1.0 : 1e3)); tot += counters[64 + 16 * w + k]; }
         fprintf(stderr, "   sum %10.0f %s\n", tot / (k == 9 ? 1.0 : 1e3), k == 9 ? "" : "kcycles");
       }
+      static const char* rn[] = {"turn: first candidate outside", "turn: window claims", "turn: after (not first choice)", "spec: survivors snapshot", "gap: release -> next token",
+                                 "(count) not first choice", "(count) late for the turn", "(count) scan behind candidates"};
+      for (int k = 0; k < 8; ++k) {
+        fprintf(stderr, "[kg spec] %-30s", rn[k]);
+        unsigned long long tot = 0;
+        for (int w = 0; w < nw; ++w) { fprintf(stderr, " %9.0f", counters[64 + 16 * 8 + 8 * w + k] / 1e3); tot += counters[64 + 16 * 8 + 8 * w + k]; }
+        fprintf(stderr, "   sum %10.0f\n", tot / 1e3);
+      }
     }
   }
   const uint32_t nclaims = header[0];

@@ -32,6 +32,7 @@ namespace kg {
 
 constexpr uint32_t KG_SPEC_LOG = 16;       // ring of the claims the last tickets touched (>= waves of the workgroup)
 constexpr uint32_t KG_SPEC_MAXW = 8;       // waves of the largest instantiation
+constexpr uint32_t KG_SPEC_SNAP = 8;       // chunks of 64 claims whose prefilter verdicts one ticket keeps in registers
 constexpr uint32_t KG_SPEC_SLOTS = 8;      // merged rows of the last tickets kept in LDS (>= the longest log window, waves - 1)
 constexpr uint32_t KG_NOSLOT = 0xFFFFFFFFu;
 constexpr uint32_t KG_SPEC_POLLS = 1u << 22;  // polls of one wait before the wave gives up (a wait is a few placements long)
@@ -46,6 +47,7 @@ struct SpecCtl {
   uint32_t last_c, last_npods, last_stamp, last_new;
   uint32_t log[KG_SPEC_LOG];  // log[e % KG_SPEC_LOG] = the claim ticket e placed its pod on, KG_NOIDX if none
   uint32_t lim_epoch;     // bumped whenever a new NodeClaim is charged against a NodePool's limits
+  unsigned long long t_rel;  // (debug timers) when the last ticket passed the token on
   uint32_t stat[8];       // 0 commits from speculation, 1 challengers evaluated, 2 rescans under the token, 3 new NodeClaims, 4 failures, 5 exact evaluations,
                           // 6 new NodeClaims / failures evaluated again under the token
 };
@@ -76,6 +78,7 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
 
 // the pod's side of the prefilter, the same value in every lane (vector registers: only vector instructions use them)
 struct PodSide {
+  uint64_t pm[KG_TWLDS];  // the pod's own type mask, zero beyond TW
   int64_t prq[4];
   uint64_t tolw, hp_conf, pzone, pct;
   uint32_t need;
@@ -96,9 +99,10 @@ __device__ __forceinline__ bool spec_prefilter(const uint64_t* pf, uint32_t pfca
   if (RANGE) {
 #pragma unroll
     for (int j = 6; j < 8; ++j) {
-      if (LDS) { h[j] = pf[(size_t)j * pfcap + cc]; KG_OPAQUE64(h[j]); }
+      if (LDS) h[j] = pf[(size_t)j * pfcap + cc];
       else h[j] = c_row[(size_t)cc * KG_ROW_WORDS + j];
     }
+    if (LDS) { KG_OPAQUE64(h[6]); KG_OPAQUE64(h[7]); }  // (after both loads are issued: one round trip)
     const uint64_t k0 = claim_key((uint32_t)(h[6] >> 32), (uint32_t)h[7], c);
     *key = k0;
     active = active && k0 > klo && k0 < khi;
@@ -106,8 +110,12 @@ __device__ __forceinline__ bool spec_prefilter(const uint64_t* pf, uint32_t pfca
   }
 #pragma unroll
   for (int j = 0; j < (RANGE ? 6 : 8); ++j) {
-    if (LDS) { h[j] = pf[(size_t)j * pfcap + cc]; KG_OPAQUE64(h[j]); }
+    if (LDS) h[j] = pf[(size_t)j * pfcap + cc];
     else h[j] = c_row[(size_t)cc * KG_ROW_WORDS + j];
+  }
+  if (LDS) {
+#pragma unroll
+    for (int j = 0; j < (RANGE ? 6 : 8); ++j) KG_OPAQUE64(h[j]);
   }
   const uint32_t tm = (uint32_t)h[6], npods = (uint32_t)(h[6] >> 32), stamp = (uint32_t)h[7];
   uint32_t bad = (uint32_t)(((ps.tolw >> (tm & 63)) & 1) == 0) | (uint32_t)((h[4] & ps.pzone) == 0) | (uint32_t)((h[5] & ps.pct) == 0);
@@ -118,14 +126,18 @@ __device__ __forceinline__ bool spec_prefilter(const uint64_t* pf, uint32_t pfca
   const bool pass1 = active && ps.hcok && bad == 0;
   uint64_t any = 0;
   if (__ballot(pass1) != 0) {  // (most claims of a late Solve are full: their option masks are never read)
+    // (every load unconditional and issued before the first use: one round trip; words beyond TW meet a zero pod word)
+    uint64_t mw[KG_TWLDS];
 #pragma unroll
     for (int k = 0; k < KG_TWLDS; ++k) {
-      if ((uint32_t)k < TW) {
-        uint64_t mw;
-        if (LDS) { mw = pf[(size_t)(8 + k) * pfcap + cc]; KG_OPAQUE64(mw); }
-        else mw = c_row[(size_t)cc * KG_ROW_WORDS + KG_ROW_MASK + k];
-        any |= mw & pc.podmask[k];
-      }
+      const uint32_t kk = (uint32_t)k < TW ? (uint32_t)k : 0u;
+      if (LDS) mw[k] = pf[(size_t)(8 + kk) * pfcap + cc];
+      else mw[k] = c_row[(size_t)cc * KG_ROW_WORDS + KG_ROW_MASK + kk];
+    }
+#pragma unroll
+    for (int k = 0; k < KG_TWLDS; ++k) {
+      if (LDS) KG_OPAQUE64(mw[k]);
+      any |= mw[k] & ps.pm[k];
     }
   }
   if (!RANGE) *key = claim_key(npods, stamp, c);
@@ -165,7 +177,7 @@ __device__ __forceinline__ void solve_spec(const DevProblem& P, const SimState& 
   constexpr size_t ORD_PAD = (16 - offsetof(SharedBase, ord) % 16) % 16;  // (a pod context is read with 16-byte loads)
   static_assert(alignof(SharedBase) % 16 == 0 && sizeof(PodCtx) % 16 == 0 && ORD_PAD + 8 * sizeof(PodCtx) <= sizeof(sh.ord), "pod contexts live in the scan-order memory");
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = KG_UNI(tid >> 6);
-  unsigned long long tk[10], tk_last = 0, ts[6] = {0, 0, 0, 0, 0, 0}, ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+  unsigned long long tk[10], tk_last = 0, ts[6] = {0, 0, 0, 0, 0, 0}, ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tra = 0, trb = 0;
 #pragma unroll
   for (int k = 0; k < 10; ++k) tk[k] = 0;
 #define KG_TK(k) do { if (DBG) { const unsigned long long n_ = clock64(); if (tk_last) tk[k] += n_ - tk_last; tk_last = n_; } } while (0)
@@ -225,9 +237,10 @@ __device__ __forceinline__ void solve_spec(const DevProblem& P, const SimState& 
   uint32_t st_fast = 0, st_chal = 0, st_rescan = 0, st_new = 0, st_fail = 0, st_exact = 0, st_refresh = 0;
 
   uint32_t cur = 0;
-  bool have_next = false;
-  uint4 nq;
+  bool have_next = false, have_next2 = false;
+  uint4 nq, nq2;
   nq.x = nq.y = nq.z = nq.w = 0;
+  nq2 = nq;
   for (uint32_t i = wave;; i += W) {
     KG_TK(8);
     // ---- wait until the Queue holds an entry for this ticket (or it is this ticket's turn and the Queue is empty)
@@ -258,13 +271,19 @@ __device__ __forceinline__ void solve_spec(const DevProblem& P, const SimState& 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the context words other lanes stored)
     // ---- the wave's next ticket: its Queue entry, context image and requests are requested now and land in the other
     // buffer when this ticket is retired
-    const bool next_ok = i + W < lds_acquire(&ctl.total_pushed);
-    uint4 ne4;
+    const uint32_t tp_seen = lds_acquire(&ctl.total_pushed);
+    const bool next_ok = i + W < tp_seen, next2_ok = i + 2 * W < tp_seen;
+    uint4 ne4, ne8;
     ne4.x = ne4.y = ne4.z = ne4.w = 0;
+    ne8 = ne4;
     uint64_t iw[4] = {0, 0, 0, 0};
     int64_t n_rq = 0;
+    // (the Queue entry after next: in registers one ticket early, so that the next ticket's context can be requested without
+    // waiting for its entry first)
+    if (next2_ok) ne8 = ((const KG_GLOBAL uint4*)S.queue)[(i + 2 * W) % QCAP];
     if (next_ok) {
-      ne4 = ((const KG_GLOBAL uint4*)S.queue)[(i + W) % QCAP];
+      if (have_next2) ne4 = nq2;
+      else ne4 = ((const KG_GLOBAL uint4*)S.queue)[(i + W) % QCAP];
       const uint32_t n_pod = KG_UNI(ne4.x), n_variant = KG_UNI(ne4.y);
       const uint64_t* img = (const uint64_t*)(P.pctx + n_variant);
 #pragma unroll
@@ -279,6 +298,10 @@ __device__ __forceinline__ void solve_spec(const DevProblem& P, const SimState& 
     ps.need = need;
 #pragma unroll
     for (int r = 0; r < 4; ++r) ps.prq[r] = pc.preq[r];
+#pragma unroll
+    for (int k = 0; k < KG_TWLDS; ++k) ps.pm[k] = pc.podmask[k];
+#pragma unroll
+    for (int k = 0; k < KG_TWLDS; ++k) { if ((uint32_t)k >= TW) ps.pm[k] = 0; KG_VREG64(ps.pm[k]); }
 
     // min key in (klo, khi) over the claims [0, n) that pass the prefilter (ranged: chunks without a claim in range are skipped)
     // The newest claims hold the fewest pods and so come first in the scan order: the chunks are visited from the highest
@@ -357,6 +380,32 @@ __device__ __forceinline__ void solve_spec(const DevProblem& P, const SimState& 
         best = k < best ? k : best;
       }
       return best;
+    };
+    // The window's verdicts, one claim at a time and AHEAD of the turn: while the wave waits, every ticket of its log window
+    // that retires has its claim's prefilter record looked at (one LDS round trip: lane j < 8 tests head word j, lane 8 + k
+    // option-mask word k); lane l keeps the claim, its key and the verdict of window entry l.  At the turn only the entry of
+    // the ticket just retired is left, and a question about the window is a ballot over these lanes.  (Claims whose record
+    // is not in LDS, or host ports: win_slow, the turn falls back to scan_window.)
+    uint32_t wv_c = KG_NOIDX, wv_done = 0;
+    uint64_t wv_key = ~0ull;
+    bool wv_ok = false, win_slow = ports_ro != nullptr;
+    auto win_eval = [&](uint32_t l) {
+      const uint32_t c = lds_relaxed(&ctl.log[(e0 + l) % KG_SPEC_LOG]);
+      if (c == KG_NOIDX) return;
+      if (c >= pfcap) { win_slow = true; return; }
+      const uint32_t j = lane < 8 + TW ? lane : 0u;
+      uint64_t w = pf[(size_t)j * pfcap + c];
+      KG_OPAQUE64(w);
+      bool bad = false, hit = false;
+      if (lane < 4) bad = ((need >> lane) & 1) && (int64_t)w < pc.preq[lane & 3];
+      else if (lane == 4) bad = (w & ps.pzone) == 0;
+      else if (lane == 5) bad = (w & ps.pct) == 0;
+      else if (lane == 6) bad = ((ps.tolw >> ((uint32_t)w & 63)) & 1) == 0;
+      else if (lane >= 8 && lane < 8 + TW) hit = (w & pc.podmask[(lane - 8) & (KG_TWLDS - 1)]) != 0;
+      const unsigned long long bb = __ballot(bad), hb = __ballot(hit);
+      const uint64_t w6 = rl64(w, 6), w7 = rl64(w, 7);
+      const uint64_t key = claim_key((uint32_t)(w6 >> 32), (uint32_t)w7, c);
+      if (lane == l) { wv_c = c; wv_key = key; wv_ok = ps.hcok && bb == 0 && hb != 0; }
     };
     // exact NodeClaim.Add of this pod on claim c -> R = the merged row.  An infeasible claim whose headroom words are older
     // than its options gets them recomputed (an upper bound of what it can still take whatever the token holder does to
@@ -466,46 +515,87 @@ __device__ __forceinline__ void solve_spec(const DevProblem& P, const SimState& 
       }
     };
 
-    // ---- speculative evaluation: the first feasible claim in scan order, on the state as this wave finds it
+    // ---- speculative evaluation, on the state as this wave finds it: the first feasible claims in scan order -- as many as
+    // it takes for one of them to be outside the log window at the turn whatever the tickets in flight do: one more than
+    // the tickets still in flight ahead of this one, not counting candidates a retired ticket of the window is known to have
+    // touched (consecutive pods of a Queue pile onto the same claims more often than not).  Every claim outside the window
+    // that comes before the last candidate (every such claim at all when the list is `complete`) is then known not to take
+    // the pod unless it is a candidate, and those verdicts hold at the turn.
     uint32_t d = KG_NOIDX;
     uint64_t keyd = ~0ull;
-    ClaimRegs Rd, Rd2;
+    ClaimRegs Rd;
     Rd.meta = 0; Rd.bits = Rd.m = 0; Rd.req = Rd.phd = 0; Rd.w6 = Rd.w7 = 0;
-    Rd2 = Rd;
-    uint32_t d2 = KG_NOIDX;
-    uint64_t keyd2 = ~0ull;
+    constexpr int KC = W < 4 ? W : 4;  // candidates kept in registers
+    ClaimRegs CR[KC];
+    uint32_t cand_c[KC];
+    uint64_t cand_k[KC];
+#pragma unroll
+    for (int q = 0; q < KC; ++q) { CR[q] = Rd; cand_c[q] = KG_NOIDX; cand_k[q] = ~0ull; }
+    uint32_t ncand = 0;
+    bool complete = false;
     FreshRegs F;
     F.valid = false; F.t = KG_NOIDX; F.reason = 0; F.lim_epoch = 0; F.meta = 0; F.bits = F.m = 0; F.req = F.hd = F.cx = 0;
     {
       const uint32_t nsnap = lds_acquire(&ctl.nclaims_vis);
-      uint64_t klo = 0;
-      while (true) {
-        const uint64_t k = scan_all(nsnap, klo);
-        if (k == ~0ull) break;
-        const uint32_t c = (uint32_t)k & 0xFFFFFu;
-        if (exact(c, KG_NOSLOT, Rd)) { d = c; keyd = k; break; }
-        klo = k;
-      }
-      if (d == KG_NOIDX) fresh(F);  // no claim takes the pod as things stand: its new NodeClaim, ahead of its turn
-      else {
-        // ... and where the pod goes if d takes another pod before this ticket's turn (consecutive pods of a Queue pile onto
-        // the same claim more often than not): d then moves to the front of the next pod-count group, so the rest of its
-        // present group comes first -- the next feasible claim of that group, evaluated now
-        const uint64_t gend = ((keyd >> 40) + 1) << 40;
-        uint64_t klo = keyd;
-        while (true) {
-          const uint64_t k = scan_range(nsnap, klo, gend);
-          if (k == ~0ull) break;
-          const uint32_t c = (uint32_t)k & 0xFFFFFu;
-          if (exact(c, KG_NOSLOT, Rd2)) { d2 = c; keyd2 = k; break; }
-          klo = k;
+      // the prefilter's survivors, once: lane l keeps the key of claim 64 b + l where it passes (records in LDS, at most
+      // KG_SPEC_SNAP chunks: larger Solves scan again for every candidate)
+      uint64_t sk[KG_SPEC_SNAP];
+      const bool snap = nsnap <= pfcap && nsnap <= 64u * KG_SPEC_SNAP;
+      if (DBG) tra = clock64();
+      if (snap) {
+#pragma unroll
+        for (int b2 = 0; b2 < (int)KG_SPEC_SNAP; ++b2) {
+          sk[b2] = ~0ull;
+          if ((uint32_t)(64 * b2) < nsnap) {
+            const uint32_t c = 64u * b2 + lane;
+            uint64_t key = 0;
+            const bool ok = spec_prefilter<true, false>(pf, pfcap, S.c_row, ports_ro, TW, c, c < nsnap, pc, ps, 0, ~0ull, &key);
+            sk[b2] = ok ? key : ~0ull;
+          }
         }
       }
+      auto next_survivor = [&](uint64_t klo) -> uint64_t {
+        if (!snap) return scan_range(nsnap, klo, ~0ull);
+        uint64_t m = ~0ull;
+#pragma unroll
+        for (int b2 = 0; b2 < (int)KG_SPEC_SNAP; ++b2) { const uint64_t v = sk[b2]; if (v > klo && v < m) m = v; }
+        if (__ballot(m != ~0ull) == 0) return ~0ull;
+        return wave_min_u64(m);
+      };
+      uint64_t klo = 0;
+      if (DBG) { trb = clock64(); tr[3] += trb - tra; }
+      while (true) {
+        // (the window's verdicts make progress here too; a candidate a retired ticket touched does not count)
+        const uint32_t cs = lds_acquire(&ctl.commit_seq);
+        while (!win_slow && e0 + wv_done < cs) { win_eval(wv_done); wv_done += 1; }
+        uint32_t safe = 0;
+#pragma unroll
+        for (int q = 0; q < KC; ++q) if ((uint32_t)q < ncand && (win_slow || __ballot(wv_c == cand_c[q]) == 0)) safe += 1;
+        if (win_slow) safe = safe > cs - e0 ? safe - (cs - e0) : 0u;
+        if (ncand == (uint32_t)KC || safe >= i - cs + 1) break;
+        if (DBG) tra = clock64();
+        const uint64_t k = next_survivor(klo);
+        if (DBG) trb = clock64();
+        if (k == ~0ull) { complete = true; break; }
+        const uint32_t c = (uint32_t)k & 0xFFFFFu;
+        ClaimRegs Rt;
+        const bool fe = exact(c, KG_NOSLOT, Rt);
+        if (fe) {
+#pragma unroll
+          for (int q = 0; q < KC; ++q) if ((uint32_t)q == ncand) { CR[q] = Rt; cand_c[q] = c; cand_k[q] = k; }
+          ncand += 1;
+        }
+        klo = k;
+      }
+      if (ncand == 0) fresh(F);  // no claim takes the pod as things stand: its new NodeClaim, ahead of its turn
     }
     KG_TK(1);
     // ---- wait for this ticket's turn
     for (uint32_t polls = 0;; ++polls) {
-      if (lds_acquire(&ctl.commit_seq) == i) break;
+      const uint32_t cs = lds_acquire(&ctl.commit_seq);
+      if (DBG && polls == 0 && cs == i) tr[6] += 1000;  // (late: the token was waiting for this wave)
+      while (!win_slow && e0 + wv_done < cs) { win_eval(wv_done); wv_done += 1; }  // (cs <= i: entries of the window only)
+      if (cs == i) break;
       if ((lds_relaxed(&ctl.done) | lds_relaxed(&ctl.err)) != 0) { stop = true; break; }
       if (polls > KG_SPEC_POLLS) { lds_store(&ctl.err, 2u); stop = true; break; }
       __builtin_amdgcn_s_sleep(1);
@@ -517,13 +607,18 @@ __device__ __forceinline__ void solve_spec(const DevProblem& P, const SimState& 
     const uint32_t qlen = tp_now - i;  // Queue length before this pop
     if (qz == epoch && qw == qlen) { lds_release(&ctl.done, 1u); break; }  // every remaining pod failed with the queue at this length
     const uint32_t nclaims = lds_relaxed(&ctl.nclaims), seq = lds_relaxed(&ctl.seq);
-    if (DBG) ts0 = clock64();
+    if (DBG) { ts0 = clock64(); if (i != 0) tr[4] += ts0 - ctl.t_rel; }
     int path = 3;
     bool d_in_window = false;  // the claim the pod lands on took a pod from a ticket of the window (its global stores may be in flight)
     {
       const uint32_t wn = i - e0;  // (< W)
       uint32_t wc = KG_NOIDX;
-      if (lane < wn) wc = ctl.log[(e0 + lane) % KG_SPEC_LOG];
+      if (win_slow) { if (lane < wn) wc = ctl.log[(e0 + lane) % KG_SPEC_LOG]; }
+      else {
+        wc = wv_c;
+        // a claim that took pods from two tickets of the window: the later entry saw it settled
+        for (uint32_t q = 1; q < wn; ++q) { const uint32_t cq = rl32(wv_c, q); if (lane < q && wv_c == cq) wv_ok = false; }
+      }
       // the LDS copy of a claim's row as the latest ticket of the window left it (KG_NOSLOT: the claim is not in the window)
       auto win_slot = [&](uint32_t c) -> uint32_t {
         const unsigned long long b = __ballot(wc == c);
@@ -531,10 +626,9 @@ __device__ __forceinline__ void solve_spec(const DevProblem& P, const SimState& 
       };
       // (debug, DevProblem::stats bit 6: no verdict of the speculative evaluation is used -- every pod is evaluated at its turn)
       const bool serial = (P.stats & 64u) != 0;
-      const bool conflict = d != KG_NOIDX && __ballot(wc == d) != 0;
       if (__builtin_expect(serial, 0)) {
         st_rescan += 1; path = 5;
-        d = KG_NOIDX; keyd = ~0ull; F.valid = false;
+        F.valid = false;
         uint64_t klo = 0;
         while (true) {
           const uint64_t k = scan_all(nclaims, klo);
@@ -547,7 +641,15 @@ __device__ __forceinline__ void solve_spec(const DevProblem& P, const SimState& 
         // challengers: claims of the window whose key lies in (klo, khi) and that take the pod, in scan order
         auto challengers = [&](uint64_t klo, uint64_t khi) -> bool {
           while (true) {
-            const uint64_t k = scan_window(wc, wn, klo, khi);
+            uint64_t k;
+            if (win_slow) k = scan_window(wc, wn, klo, khi);
+            else {
+              k = ~0ull;
+              for (unsigned long long q = __ballot(wv_ok && wv_key > klo && wv_key < khi); q; q &= q - 1) {
+                const uint64_t kq = rl64(wv_key, (uint32_t)(__ffsll(q) - 1));
+                k = kq < k ? kq : k;
+              }
+            }
             if (k == ~0ull) return false;
             st_chal += 1;
             const uint32_t c = (uint32_t)k & 0xFFFFFu;
@@ -556,50 +658,44 @@ __device__ __forceinline__ void solve_spec(const DevProblem& P, const SimState& 
             klo = k;
           }
         };
-        // every claim (settled state) whose key lies in (klo, khi), in scan order
-        auto finish_scan = [&](uint64_t klo, uint64_t khi, uint32_t skip) -> bool {
-          while (true) {
+        // The candidates outside the window kept their verdicts; the first of them bounds what else matters: the claims of
+        // the window (the pod's own earlier choices among them, where they are NOW), evaluated on their settled rows in scan
+        // order up to it.  With every candidate in the window and the list cut short, the claims behind the last candidate
+        // were never looked at: scanned now.
+        uint32_t jstar = KG_NOIDX;
+#pragma unroll
+        for (int q = KC - 1; q >= 0; --q) if ((uint32_t)q < ncand && __ballot(wc == cand_c[q]) == 0) jstar = (uint32_t)q;
+        uint64_t bound = ~0ull;
+#pragma unroll
+        for (int q = 0; q < KC; ++q) if ((uint32_t)q == jstar) bound = cand_k[q];
+        if (DBG) tra = clock64();
+        const bool taken = challengers(0, bound);
+        if (DBG) { trb = clock64(); tr[0] += tra - ts0; tr[1] += trb - tra; }
+        if (taken && jstar == 0) path = 4;
+        else if (taken) path = 5;
+        else if (jstar != KG_NOIDX) {
+#pragma unroll
+          for (int q = 0; q < KC; ++q) if ((uint32_t)q == jstar) { d = cand_c[q]; keyd = cand_k[q]; Rd = CR[q]; }
+          if (jstar == 0) st_fast += 1; else path = 5;
+        } else if (ncand != 0) path = 5;
+        if (jstar == KG_NOIDX && ncand != 0 && !complete) {
+          // (more tickets in flight than candidates kept: what lies between the last candidate and the window claim that took
+          // the pod -- or the end -- was never looked at)
+          uint64_t klo = 0;
+#pragma unroll
+          for (int q = 0; q < KC; ++q) if ((uint32_t)q + 1 == ncand) klo = cand_k[q];
+          const uint64_t khi = keyd;  // (all ones when no window claim took it)
+          if (DBG) tr[7] += 1000;
+          while (klo < khi) {
             const uint64_t k = scan_range(nclaims, klo, khi);
-            if (k == ~0ull) return false;
+            if (k == ~0ull) break;
             const uint32_t c = (uint32_t)k & 0xFFFFFu;
             klo = k;
-            if (c == skip) continue;
             ClaimRegs Rc;
-            if (exact(c, win_slot(c), Rc)) { d = c; keyd = k; Rd = Rc; return true; }
+            if (exact(c, win_slot(c), Rc)) { d = c; keyd = k; Rd = Rc; break; }
           }
-        };
-        // 1. claims of the window that now come before the pod's choice (any of them, if it has none)
-        const bool taken = challengers(0, keyd);
-        if (taken) path = 4;
-        if (!taken && conflict) {
-          // The chosen claim d took a pod meanwhile and moved to the front of the next pod-count group.  What comes before
-          // its new place: 2. window claims that joined the rest of its old group, 3. the claim d2 of that rest the
-          // speculative evaluation found feasible, 4. window claims that entered the next group after d did; then d itself on
-          // its settled row.  (Claims outside the window were evaluated ahead of the turn, and their verdicts hold.)
-          st_rescan += 1; path = 5;
-          const uint64_t key_old = keyd;
-          const uint32_t d0 = d, np_old = (uint32_t)(key_old >> 40);
-          const uint64_t gend = (uint64_t)(np_old + 1) << 40;
-          // (where d is now: from the LDS copy of its row -- its record may have been read before or after the window's commits)
-          const uint32_t slot0 = win_slot(d0);
-          uint64_t c6 = rowc[(size_t)slot0 * KG_ROW_WORDS + 6], c7 = rowc[(size_t)slot0 * KG_ROW_WORDS + 7];
-          KG_OPAQUE64(c6); KG_OPAQUE64(c7);
-          const uint64_t key_cur = claim_key((uint32_t)(KG_UNI64(c6) >> 32), (uint32_t)KG_UNI64(c7), d0);
-          if (key_cur == key_old) {
-            // the speculative evaluation already met d where it is now (but maybe half-written): d again, then on from there
-            if (!exact(d0, slot0, Rd)) { d = KG_NOIDX; keyd = ~0ull; finish_scan(key_old, ~0ull, d0); }
-          } else if (!challengers(key_old, d2 != KG_NOIDX ? keyd2 : gend)) {
-            if (d2 != KG_NOIDX && __ballot(wc == d2) == 0) { d = d2; keyd = keyd2; Rd = Rd2; }
-            else {
-              const bool feas = exact(d0, win_slot(d0), Rd);
-              const uint64_t key_new = feas ? claim_key((uint32_t)(Rd.w6 >> 32), (uint32_t)Rd.w7, d0) : ~0ull;
-              if (!feas) d = KG_NOIDX;
-              if (d2 != KG_NOIDX) finish_scan(key_old, key_new, d0);                    // (d2 is in the window too: from d's old place on)
-              else if (feas && (uint32_t)(Rd.w6 >> 32) == np_old + 1) challengers(gend - 1, key_new);
-              else finish_scan(gend - 1, key_new, d0);                                   // (d is full now, or took two pods)
-            }
-          }
-        } else if (!taken && d != KG_NOIDX) st_fast += 1;
+        }
+        if (path == 5) { st_rescan += 1; if (DBG) { tr[2] += clock64() - trb; tr[5] += 1000; } }
       }
       d_in_window = d != KG_NOIDX && __ballot(wc == d) != 0;
     }
@@ -715,6 +811,7 @@ __device__ __forceinline__ void solve_spec(const DevProblem& P, const SimState& 
     // global memory, and waited for it above); the release orders it before the token
     if (DBG) ts2 = clock64();
     if (lane == 0) ctl.log[i % KG_SPEC_LOG] = logc;
+    if (DBG && lane == 0) ctl.t_rel = clock64();
     if (lane == 0) lds_release(&ctl.commit_seq, i + 1);
     if (DBG) { ts3 = clock64(); if (path == 3) { ts[0] += ts0 - tk_last; ts[1] += ts1 - ts0; ts[2] += ts2 - ts1; ts[3] += ts3 - ts2; } else if (path == 5) { ts[4] += ts1 - ts0; ts[5] += ts3 - ts1; } }
     // ================= token passed on
@@ -755,6 +852,8 @@ __device__ __forceinline__ void solve_spec(const DevProblem& P, const SimState& 
     }
     // ---- the next ticket's context -> the other buffer
     have_next = next_ok;
+    have_next2 = next2_ok;
+    nq2 = ne8;
     if (next_ok) {
       __attribute__((address_space(3))) uint64_t* dst = (__attribute__((address_space(3))) uint64_t*)(cur ? mybuf[0] : mybuf[1]);
       const unsigned long long nb = __ballot(n_rq != 0);
@@ -796,6 +895,8 @@ __device__ __forceinline__ void solve_spec(const DevProblem& P, const SimState& 
     for (int k = 0; k < 10; ++k) Se.counters[64 + 16 * wave + k] = tk[k];
 #pragma unroll
     for (int k = 0; k < 6; ++k) Se.counters[64 + 16 * wave + 10 + k] = ts[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) Se.counters[64 + 16 * KG_SPEC_MAXW + 8 * wave + k] = tr[k];
   }
   if (tid == 0) {
     Se.header[0] = nclaims; Se.header[1] = ctl.relax;

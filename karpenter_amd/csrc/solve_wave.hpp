@@ -151,7 +151,9 @@ __device__ __forceinline__ bool wave_add(const DevProblem& P, const KG_CONST Dev
   uint64_t tmk[KG_MAXR];
   if (thr_rows) {
 #pragma unroll
-    for (int r = 0; r < KG_MAXR; ++r) { tmk[r] = thr_rows[rl32(lrow, 8 * r) * TW + w]; KG_OPAQUE64(tmk[r]); }  // (row 0 for unused lanes)
+    for (int r = 0; r < KG_MAXR; ++r) tmk[r] = thr_rows[rl32(lrow, 8 * r) * TW + w];  // (row 0 for unused lanes)
+#pragma unroll
+    for (int r = 0; r < KG_MAXR; ++r) KG_OPAQUE64(tmk[r]);  // (after the last load is issued: one round trip, not eight)
   } else {
     const DevProblem& Pt = rare_view(Pk);  // (the fit-threshold rows did not fit the LDS pool)
 #pragma unroll
@@ -202,7 +204,15 @@ __device__ __forceinline__ bool wave_add(const DevProblem& P, const KG_CONST Dev
       if (changed && present) {
         uint64_t f = P.kN[(size_t)a * TW + w];
         if (op_neg(opclass(sp.meta & RM_COMPL, sp.word != 0))) { const DevProblem& Pb = rare_view(Pk); f |= Pb.kU[(size_t)a * TW + w]; }
-        for (uint64_t q = hm & ((1ull << KG_SPV) - 1); q; q &= q - 1) { uint64_t g = sh.stw[i][ctz64(q)][w]; KG_OPAQUE64(g); f |= g; }
+        {
+          // (KG_SPV rows at most, every load issued before the first use)
+          uint64_t g[KG_SPV];
+          const uint64_t hq = hm & ((1ull << KG_SPV) - 1);
+#pragma unroll
+          for (int v = 0; v < (int)KG_SPV; ++v) g[v] = sh.stw[i][v][w];
+#pragma unroll
+          for (int v = 0; v < (int)KG_SPV; ++v) { KG_OPAQUE64(g[v]); f |= ((hq >> v) & 1) ? g[v] : 0ull; }
+        }
         m &= f;
       }
       if (i == P.slot_zone || i == P.slot_ct || i == P.slot_zid) off_use = off_use || changed;
