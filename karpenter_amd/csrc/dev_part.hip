@@ -13,20 +13,21 @@ namespace kg {
 
 #if KG_PART == 0 || KG_PART == 1
 // k_solve: one workgroup = one Scheduler.Solve (persistent over the whole pod queue)
-template <int NT, bool DBG>
+template <int NT, bool DBG, bool TPF = true>
 __global__ void __launch_bounds__(NT) k_solve(DevProblem Pin, const SimState* sims, const uint32_t* nqueue) {
   __shared__ Shared sh;
   const DevProblem& P = Pin;
   const SimState S = sims[blockIdx.x];
   const unsigned long long c0 = clock64(), w0 = wall_clock64();
-  solve_block<NT, DBG>(P, S, sh, nqueue[blockIdx.x]);
+  solve_block<NT, DBG, TPF>(P, S, sh, nqueue[blockIdx.x]);
   if (DBG && (P.stats & 2) && threadIdx.x == 0) { S.counters[24] = clock64() - c0; S.counters[25] = wall_clock64() - w0; }
 }
 #if KG_PART == 0
 void enqueue_k_solve_main(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, bool dbg, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (dbg) hipLaunchKernelGGL((k_solve<256, true>), dim3(nsims), dim3(256), 0, st, P, sims, nqueue);
-  else hipLaunchKernelGGL((k_solve<256, false>), dim3(nsims), dim3(256), 0, st, P, sims, nqueue);
+  else if (P.G > 0 || P.GH > 0) hipLaunchKernelGGL((k_solve<256, false, true>), dim3(nsims), dim3(256), 0, st, P, sims, nqueue);
+  else hipLaunchKernelGGL((k_solve<256, false, false>), dim3(nsims), dim3(256), 0, st, P, sims, nqueue);  // (no topology groups: without their prefilter code)
 }
 #else
 void enqueue_k_solve_wide(const DevProblem& P, const SimState* sims, int nsims, const uint32_t* nqueue, int block, void* stream) {
@@ -51,30 +52,35 @@ static_assert(sim_lds_bytes(512) <= 64 * 1024, "dynamic LDS without an opt-in at
 extern __shared__ __align__(16) unsigned char sim_lds[];
 // OCC: workgroups per CU the register budget allows.  3 (168 registers, a few dozen spilled) for a batch that fills the
 // chip more than twice over; 2 (256 registers, none spilled) for a small batch, whose time is its longest simulation.
-template <int NT, bool DBG, int OCC>
+// TPF: solve_block's topology prefilter compiled in (batches whose problem has topology groups)
+template <int NT, bool DBG, int OCC, bool TPF>
 __global__ void __launch_bounds__(NT, OCC) k_simulate(DevProblem Pin, const SimState* sims, const uint32_t* nqueue) {
   Shared& sh = *reinterpret_cast<Shared*>(sim_lds);
   const DevProblem& P = Pin;
   const SimState S = sims[blockIdx.x];
-  solve_block<NT, DBG>(P, S, sh, nqueue[blockIdx.x]);
+  solve_block<NT, DBG, TPF>(P, S, sh, nqueue[blockIdx.x]);
 }
 #if KG_PART == 2
 void enqueue_k_simulate_main(const DevProblem& Pin, const SimState* sims, int nsims, const uint32_t* nqueue, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   DevProblem P = Pin;
   P.gp_cap = sim_gp_cap(256);
-  if (nsims > 2 * 256)  // (256 CUs: more simulations than two per CU)
-    hipLaunchKernelGGL((k_simulate<256, false, 3>), dim3(nsims), dim3(256), sim_lds_bytes(256), st, P, sims, nqueue);
-  else
-    hipLaunchKernelGGL((k_simulate<256, false, 2>), dim3(nsims), dim3(256), sim_lds_bytes(256), st, P, sims, nqueue);
+  const bool topo = P.G > 0 || P.GH > 0;
+  if (nsims > 2 * 256) {  // (256 CUs: more simulations than two per CU)
+    if (topo) hipLaunchKernelGGL((k_simulate<256, false, 3, true>), dim3(nsims), dim3(256), sim_lds_bytes(256), st, P, sims, nqueue);
+    else hipLaunchKernelGGL((k_simulate<256, false, 3, false>), dim3(nsims), dim3(256), sim_lds_bytes(256), st, P, sims, nqueue);
+  } else {
+    if (topo) hipLaunchKernelGGL((k_simulate<256, false, 2, true>), dim3(nsims), dim3(256), sim_lds_bytes(256), st, P, sims, nqueue);
+    else hipLaunchKernelGGL((k_simulate<256, false, 2, false>), dim3(nsims), dim3(256), sim_lds_bytes(256), st, P, sims, nqueue);
+  }
 }
 #else
 void enqueue_k_simulate_other(const DevProblem& Pin, const SimState* sims, int nsims, const uint32_t* nqueue, bool dbg, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   DevProblem P = Pin;
   P.gp_cap = sim_gp_cap(dbg ? 256 : 512);
-  if (dbg) hipLaunchKernelGGL((k_simulate<256, true, 1>), dim3(nsims), dim3(256), sim_lds_bytes(256), st, P, sims, nqueue);
-  else hipLaunchKernelGGL((k_simulate<512, false, 1>), dim3(nsims), dim3(512), sim_lds_bytes(512), st, P, sims, nqueue);
+  if (dbg) hipLaunchKernelGGL((k_simulate<256, true, 1, true>), dim3(nsims), dim3(256), sim_lds_bytes(256), st, P, sims, nqueue);
+  else hipLaunchKernelGGL((k_simulate<512, false, 1, true>), dim3(nsims), dim3(512), sim_lds_bytes(512), st, P, sims, nqueue);
 }
 #endif
 #endif

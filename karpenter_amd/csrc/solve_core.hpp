@@ -1369,7 +1369,10 @@ KG_HD void stage_tables(const DevProblem& P, SharedBase& sh) {
 // a slow wave has not branched yet, and the waves' barrier counts diverge.  Words written once per pass alternate
 // between two slots for that reason (feas, mvf, fresh_lim).
 // DBG: with the phase timers and the per-wave cycle accounting (debug builds of the kernel only: their counters cost registers)
-template <int NT, bool DBG>
+// TPF: with the topology groups / empty-requirement shortcut in the NodeClaim prefilter.  A batch of simulations without
+// topology groups runs the instantiation without them: the extra code is never executed there, but its registers cost the
+// existing-node path a third of its speed (k_simulate on C4: 0.50 -> 0.68 ms with it).
+template <int NT, bool DBG, bool TPF = true>
 KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint32_t n_queue) {
   const bool STATS = (P.stats & 1) != 0;
   const bool TIMERS = DBG && (P.stats & 2) != 0;  // per-phase wall-clock ticks (100 MHz) of thread 0 into counters[8..]
@@ -1516,8 +1519,8 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     // claims already pinned to a full zone).  What can be decided per claim from one or two words is decided there.
     // a pod whose own requirements rule out no instance type (no selector, no affinity terms: every replica of a plain
     // deployment) intersects every claim's options -- a claim always has some -- so the prefilter leaves the option words alone
-    const bool pm_all = KG_UNI(pc.vc.v.pm_all) != 0;
-    const bool topo_pf = !STATS && KG_UNI(pc.vc.nlist) != 0;
+    const bool pm_all = TPF && KG_UNI(pc.vc.v.pm_all) != 0;
+    const bool topo_pf = TPF && !STATS && KG_UNI(pc.vc.nlist) != 0;
     if (topo_pf) {
       KG_FOR_THREADS(tid, NT) { if ((uint32_t)tid < pc.vc.nlist) sh.tallow[tid] = topo_allow(P, S, pc.vc.lst[tid].g, pc.vc.lst[tid].le); }
       KG_SYNCW(0);
