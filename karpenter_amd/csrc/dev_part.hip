@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(NT, OCC) k_simulate(DevProblem Pin, const SimS
   Shared& sh = *reinterpret_cast<Shared*>(sim_lds);
   const DevProblem& P = Pin;
   const SimState S = sims[blockIdx.x];
-  solve_block<NT, DBG, TPF>(P, S, sh, nqueue[blockIdx.x]);
+  solve_block<NT, DBG, TPF, false>(P, S, sh, nqueue[blockIdx.x]);
 }
 #if KG_PART == 2
 void enqueue_k_simulate_main(const DevProblem& Pin, const SimState* sims, int nsims, const uint32_t* nqueue, void* stream) {

@@ -45,6 +45,7 @@ constexpr int KG_NTMAX = 1024;    // threads of the largest workgroup solve_bloc
 constexpr int KG_GP0 = 8;         // ... in the first pass over a chunk of the scan order
 constexpr int KG_ROWW = 64;       // requirement-value words of one claim row
 constexpr int KG_TWLDS = 16;      // option-mask words (<= 1024 instance types) for the tables staged in LDS
+constexpr int KG_NSCAN = 4;       // chunks of existing nodes one barrier of a Solve's dense scan covers
 constexpr int KG_SPV = 16;        // values per special key whose value->types rows are staged in LDS
 constexpr int KG_OFFROWS = 32;    // (zone, capacity-type) offering rows staged in LDS
 constexpr uint32_t KG_NOIDX = 0xFFFFFFFFu;
@@ -1372,7 +1373,9 @@ KG_HD void stage_tables(const DevProblem& P, SharedBase& sh) {
 // TPF: with the topology groups / empty-requirement shortcut in the NodeClaim prefilter.  A batch of simulations without
 // topology groups runs the instantiation without them: the extra code is never executed there, but its registers cost the
 // existing-node path a third of its speed (k_simulate on C4: 0.50 -> 0.68 ms with it).
-template <int NT, bool DBG, bool TPF = true>
+// NBD: one Solve over its own nfree (never a batch of simulations): the existing-node scan of a pod without topology groups
+// looks at KG_NSCAN chunks of NT nodes per barrier (dense_scan below).
+template <int NT, bool DBG, bool TPF = true, bool NBD = true>
 KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint32_t n_queue) {
   const bool STATS = (P.stats & 1) != 0;
   const bool TIMERS = DBG && (P.stats & 2) != 0;  // per-phase wall-clock ticks (100 MHz) of thread 0 into counters[8..]
@@ -1459,6 +1462,58 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     need = KG_UNI(need);
     KG_T(0);
     // ---- existing nodes, first feasible in scan order
+    // One Solve, a pod without topology groups: every thread looks at KG_NSCAN nodes (one per chunk of NT) with all their
+    // words requested before the first test -- one round trip and one barrier for KG_NSCAN chunks.  Late in a Solve no node
+    // takes anything any more and every pod walks them all: the walk is then KG_NSCAN times shorter (C5: 2 000 nodes).
+    const bool dense_scan = NBD && !P.sparse_nodes && KG_UNI(pc.vc.nlist) == 0;
+    if (dense_scan) {
+      const Variant& v = pc.vc.v;
+      for (uint32_t base = 0; base < (uint32_t)P.N; base += NT * KG_NSCAN) {
+        KG_W(16);
+        const bool pf_word = want_pf && ctx_word_per_thread<NT>(P);
+        KG_FOR_THREADS(tid, NT) {
+          uint64_t cword = 0;
+          uint4 q2;
+          q2.x = q2.y = q2.z = q2.w = 0;
+          if (pf_word) cword = ctx_word_load(P, tid, qe_next.x, qe_next.y);
+          if (want_pf && want_q2 && tid == NT - 1) q2 = ((const KG_GLOBAL uint4*)S.queue)[q2_pos];
+          uint64_t we[KG_NSCAN], wt[KG_NSCAN], wl[KG_NSCAN], wp[KG_NSCAN];
+          int64_t nf[KG_NSCAN][KG_MAXR];
+#pragma unroll
+          for (int j = 0; j < KG_NSCAN; ++j) {
+            const uint32_t n = base + (uint32_t)j * NT + tid, nn = n < (uint32_t)P.N ? n : 0u, wi = nn >> 6;  // (every load unconditional)
+            we[j] = S.excl[wi];
+            wt[j] = P.ntol[(size_t)v.tolset * P.NW + wi];
+            wl[j] = P.nlab[(size_t)v.rs * P.NW + wi];
+            wp[j] = P.has_ports ? S.nports[nn] : 0ull;
+#pragma unroll
+            for (int r = 0; r < KG_MAXR; ++r) {
+              nf[j][r] = 0;
+              if ((need >> r) & 1) nf[j][r] = S.nfree[(size_t)r * P.N + nn];
+            }
+          }
+          uint32_t mine = KG_NOIDX;
+#pragma unroll
+          for (int j = KG_NSCAN - 1; j >= 0; --j) {
+            const uint32_t n = base + (uint32_t)j * NT + tid, bi = n & 63;
+            bool ok = n < (uint32_t)P.N && !((we[j] >> bi) & 1) && ((wt[j] >> bi) & 1) && ((wl[j] >> bi) & 1) && !(wp[j] & pc.vc.hp_conf);
+#pragma unroll
+            for (int r = 0; r < KG_MAXR; ++r) ok = ok && (!((need >> r) & 1) || pc.preq[r] <= nf[j][r]);
+            mine = ok ? n : mine;
+          }
+          if (mine != KG_NOIDX) { scan_ntk(sh)[tid] = -1; atomic_min_u32(&sh.best2[bslot], mine); }
+          KG_W(17);
+          if (tid == 0) sh.best2[bslot ^ 1] = KG_NOIDX;  // (last read one placement ago)
+          if (pf_word) ctx_word_store(P, nx, tid, cword);
+          else if (want_pf) ctx_fetch<NT>(P, nx, tid, qe_next.x, qe_next.y);
+          if (want_pf && want_q2 && tid == NT - 1) sh.qn[bslot] = q2;
+          KG_W(18);
+        }
+        if (want_pf) { want_pf = false; ctx_ready = true; q2_ready = want_q2; }
+        KG_SYNCW(6);
+        if (KG_UNI(sh.best2[bslot]) != KG_NOIDX) break;
+      }
+    } else
     for (uint32_t base = 0; base < (uint32_t)P.N; base += NT) {
       KG_W(16);
       const bool pf_word = want_pf && ctx_word_per_thread<NT>(P);
