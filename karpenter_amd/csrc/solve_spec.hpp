@@ -525,7 +525,7 @@ __device__ __forceinline__ void solve_spec(const DevProblem& P, const SimState& 
     uint64_t keyd = ~0ull;
     ClaimRegs Rd;
     Rd.meta = 0; Rd.bits = Rd.m = 0; Rd.req = Rd.phd = 0; Rd.w6 = Rd.w7 = 0;
-    constexpr int KC = W < 4 ? W : 4;  // candidates kept in registers
+    constexpr int KC = W < 6 ? W : 6;  // candidates kept in registers
     ClaimRegs CR[KC];
     uint32_t cand_c[KC];
     uint64_t cand_k[KC];
