@@ -19,7 +19,7 @@ __global__ void __launch_bounds__(NT) k_solve(DevProblem Pin, const SimState* si
   const DevProblem& P = Pin;
   const SimState S = sims[blockIdx.x];
   const unsigned long long c0 = clock64(), w0 = wall_clock64();
-  solve_block<NT, DBG, TPF>(P, S, sh, nqueue[blockIdx.x]);
+  solve_block<NT, DBG, TPF>(P, S, sh, nqueue[blockIdx.x], (const KG_CONST4 DevProblem*)__builtin_amdgcn_kernarg_segment_ptr(), (const KG_CONST4 SimState*)(sims + blockIdx.x));
   if (DBG && (P.stats & 2) && threadIdx.x == 0) { S.counters[24] = clock64() - c0; S.counters[25] = wall_clock64() - w0; }
 }
 #if KG_PART == 0
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(NT, OCC) k_simulate(DevProblem Pin, const SimS
   Shared& sh = *reinterpret_cast<Shared*>(sim_lds);
   const DevProblem& P = Pin;
   const SimState S = sims[blockIdx.x];
-  solve_block<NT, DBG, TPF, false>(P, S, sh, nqueue[blockIdx.x]);
+  solve_block<NT, DBG, TPF, false>(P, S, sh, nqueue[blockIdx.x], (const KG_CONST4 DevProblem*)__builtin_amdgcn_kernarg_segment_ptr(), (const KG_CONST4 SimState*)(sims + blockIdx.x));
 }
 #if KG_PART == 2
 void enqueue_k_simulate_main(const DevProblem& Pin, const SimState* sims, int nsims, const uint32_t* nqueue, void* stream) {

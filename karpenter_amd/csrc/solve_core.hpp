@@ -45,6 +45,11 @@ constexpr int KG_NTMAX = 1024;    // threads of the largest workgroup solve_bloc
 constexpr int KG_GP0 = 8;         // ... in the first pass over a chunk of the scan order
 constexpr int KG_ROWW = 64;       // requirement-value words of one claim row
 constexpr int KG_TWLDS = 16;      // option-mask words (<= 1024 instance types) for the tables staged in LDS
+#if KG_DEVICE_ONLY
+#define KG_CONST4 __attribute__((address_space(4)))
+#else
+#define KG_CONST4
+#endif
 constexpr int KG_NSCAN = 4;       // chunks of existing nodes one barrier of a Solve's dense scan covers
 constexpr int KG_SPV = 16;        // values per special key whose value->types rows are staged in LDS
 constexpr int KG_OFFROWS = 32;    // (zone, capacity-type) offering rows staged in LDS
@@ -1375,8 +1380,13 @@ KG_HD void stage_tables(const DevProblem& P, SharedBase& sh) {
 // existing-node path a third of its speed (k_simulate on C4: 0.50 -> 0.68 ms with it).
 // NBD: one Solve over its own nfree (never a batch of simulations): the existing-node scan of a pod without topology groups
 // looks at KG_NSCAN chunks of NT nodes per barrier (dense_scan below).
+// Pk / Sk (device builds): the same two descriptors where they lie in memory (kernel-argument segment, state image), typed
+// in the constant address space.  Every placement reads its fields through a view that is made opaque at the top of the
+// loop, so the scalar loads stay inside the placement: about 130 pointers and sizes no longer live (parked in VGPR lanes,
+// a v_readlane per use) across the whole Solve.
 template <int NT, bool DBG, bool TPF = true, bool NBD = true>
-KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint32_t n_queue) {
+KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint32_t n_queue, const KG_CONST4 DevProblem* Pk = nullptr,
+                       const KG_CONST4 SimState* Sk = nullptr) {
   const bool STATS = (P.stats & 1) != 0;
   const bool TIMERS = DBG && (P.stats & 2) != 0;  // per-phase wall-clock ticks (100 MHz) of thread 0 into counters[8..]
   unsigned long long t_mark = 0;
@@ -1422,6 +1432,13 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
   uint32_t fpass = 0, endk_fast = 0;                // wave-local passes so far; the winner's group end when such a pass found it
   bool fast_win = false;
   while (true) {
+#if KG_DEVICE_ONLY && !defined(KG_NO_LOOP_VIEW)
+    const KG_CONST4 DevProblem* pk_ = Pk;
+    const KG_CONST4 SimState* sk_ = Sk;
+    asm volatile("" : "+s"(pk_), "+s"(sk_));
+    const DevProblem& P = *(const DevProblem*)pk_;  // (shadows the by-value copies inside the placement)
+    const SimState& S = *(const SimState*)sk_;
+#endif
     // ---- Queue.Pop
     if (qlen == 0) break;
     uint4 qe;
