@@ -242,6 +242,11 @@ __device__ __forceinline__ void solve_spec(const DevProblem& P, const SimState& 
   nq.x = nq.y = nq.z = nq.w = 0;
   nq2 = nq;
   for (uint32_t i = wave;; i += W) {
+#ifndef KG_NO_LOOP_VIEW
+    // (the descriptors through per-ticket views: their fields' scalar loads stay inside the ticket -- solve_core.hpp)
+    const DevProblem& P = rare_view(Pk);
+    const SimState& S = rare_view(Sk);
+#endif
     KG_TK(8);
     // ---- wait until the Queue holds an entry for this ticket (or it is this ticket's turn and the Queue is empty)
     bool stop = false;

@@ -402,6 +402,11 @@ __device__ __forceinline__ void solve_wave(const DevProblem& P, const SimState& 
   uint4 q2;
   q2.x = q2.y = q2.z = q2.w = 0;
   while (qlen != 0) {
+#ifndef KG_NO_LOOP_VIEW
+    // (the descriptors through per-placement views: their fields' scalar loads stay inside the placement -- solve_core.hpp)
+    const DevProblem& P = rare_view(Pk);
+    const SimState& S = rare_view(Sk);
+#endif
     // ---- Queue.Pop
     KG_W(7);
     // (the head's entry and context were fetched during the previous placement unless the queue was too short then)
