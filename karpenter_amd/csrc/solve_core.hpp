@@ -1187,6 +1187,56 @@ __device__ __forceinline__ void fast_eval_wave(const DevProblem& P, const SimSta
     if (chg) ent_changed |= 1u << j;
     if (spec >= 0 && chg) sp_changed |= 1u << spec;
   }
+  // ---- step 4: Topology.AddRequirements on the merged row (row_topology's arithmetic; every lane runs it on the same values,
+  // lane i keeps the domains the groups leave for special key i), then the result merged into the row
+  const uint32_t nlist = KG_UNI(pc.vc.nlist);
+  if (ok && nlist != 0) {
+    uint64_t topo_l = ~0ull;
+    uint32_t has_topo = 0;
+    const uint32_t hslot = (uint32_t)P.N + c;
+    bool tok = true;
+    for (uint32_t li = 0; li < nlist && tok; ++li) {
+      const ListEntry le = pc.vc.lst[li].le;
+      const Group g = pc.vc.lst[li].g;
+      const bool self = le.flags & LF_SELF;
+      const uint32_t gsp = KG_UNI((uint32_t)g.spec);
+      if (gsp == 0xFF) { if (KG_UNI((uint32_t)topo_host(S, P, g, self, hslot)) == 0) tok = false; continue; }
+      const uint64_t podDom = ((uint64_t)le.poddom_hi << 32) | le.poddom_lo;
+      const uint32_t a = rl32(spa, gsp);
+      SReq cur;
+      cur.meta = rl32(meta, a);
+      cur.word = (cur.meta & RM_PRESENT) ? rl64(bits, rl32(spoff, gsp)) : 0;
+      const uint64_t nodeDom = has_mask1(P, (int)a, cur);
+      const TopoOut o = topo_small(P, S, g, le.g, self, podDom, nodeDom);
+      if (KG_UNI((uint32_t)o.ok) == 0) { tok = false; break; }
+      if (lane == gsp) topo_l &= o.opts;
+      has_topo |= 1u << gsp;
+    }
+    for (int i = 0; i < P.nspec && tok; ++i) {
+      if (!((has_topo >> i) & 1)) continue;
+      const uint32_t a = rl32(spa, (uint32_t)i), off = rl32(spoff, (uint32_t)i);
+      SReq cur;
+      cur.meta = rl32(meta, a);
+      cur.word = (cur.meta & RM_PRESENT) ? rl64(bits, off) : 0;
+      const SReq inc{rm_make(false, 0, 0), rl64(topo_l, (uint32_t)i)};
+      SReq out;
+      if (!(cur.meta & RM_PRESENT)) {
+        // receiver lacks the key: allowed when well-known or the incoming operator is DoesNotExist
+        if (!((P.well_known_slots >> a) & 1) && inc.word != 0) { tok = false; break; }
+        out = inc;
+        sp_changed |= 1u << i;
+      } else {
+        out = intersect1(P, (int)a, cur, inc);
+        const bool empty = !(out.meta & RM_COMPL) && out.word == 0;
+        const int eop = opclass(cur.meta & RM_COMPL, cur.word != 0);
+        if (empty && !op_neg(eop)) { tok = false; break; }
+        if (out.word != cur.word || out.meta != cur.meta) sp_changed |= 1u << i;
+      }
+      if (lane == off) bits = out.word;
+      if (lane == a) meta = out.meta;
+    }
+    if (!tok) { ok = false; if (lane == 0) sh.pf_topo = 1; }
+  }
   KG_FT(44);
   // ---- step 5: requests including the pod; the fit threshold of every resource at once, by 8-ary search in its lanes
   const int64_t nr = req + add;
@@ -1601,8 +1651,8 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
     uint32_t stage = 0, tnext = 0, base = 0, result = 0, win_g = 0;
     fast_win = false;
 #if KG_DEVICE_ONLY
-    // the wave-local NodeClaim.Add covers pods without topology groups when the tables are staged in LDS
-    const bool fast_pod = !STATS && !(P.stats & 4) && P.tmpl_minv_mask == 0 && KG_UNI(pc.vc.nlist) == 0 && P.TW <= KG_TWLDS && P.Ka <= KG_MAXKA &&
+    // the wave-local NodeClaim.Add (topology groups included) applies when the tables are staged in LDS
+    const bool fast_pod = !STATS && !(P.stats & 4) && P.tmpl_minv_mask == 0 && P.TW <= KG_TWLDS && P.Ka <= KG_MAXKA &&
                           P.Wa <= 64 && KG_UNI(sh.thr_lds) && KG_UNI(sh.stw_lds) && KG_UNI(sh.off_lds);
 #endif
     while (stage != 2) {
