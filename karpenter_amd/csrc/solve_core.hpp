@@ -789,10 +789,12 @@ KG_HD bool row_compatible_rs(const DevProblem& P, const Shared& sh, const Row& R
 }
 
 // Topology.Record for a pod placed on the claim of row R (after the commit of its requirements)
-KG_HD void row_record_topology(const DevProblem& P, const SimState& S, const Shared& sh, const PodCtx& pc, const Row& R) {
+// (entries [first, record_cnt) in steps of `step`: the commit gives every entry of the pod's record list a lane of its own --
+// the entries name different groups, and each is two or three dependent round trips to the group's counters)
+KG_HD void row_record_topology(const DevProblem& P, const SimState& S, const Shared& sh, const PodCtx& pc, const Row& R, uint32_t first = 0, uint32_t step = 1) {
   const Variant& v = pc.vc.v;
   const uint32_t hslot = P.N + R.c;
-  for (uint32_t li = 0; li < v.record_cnt; ++li) {
+  for (uint32_t li = first; li < v.record_cnt; li += step) {
     const ListEntry le = P.lists[v.record_off + li];
     const Group g = P.groups[le.g];
     if (!(le.flags & LF_INVERSE) && g.filter_cnt) {
@@ -2038,8 +2040,8 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
           S.c_stamp[c] = seq + 1;
           S.pod_kind[pod_row(S, pod)] = 2;
           S.pod_index[pod_row(S, pod)] = (int32_t)c;
-          row_record_topology(P, S, sh, pc, R);
         }
+        if (tid >= NT / 2 && tid < NT / 2 + 64) row_record_topology(P, S, sh, pc, R, (uint32_t)(tid - NT / 2), 64u);
         // scan order -> the other buffer
         for (uint32_t p = tid; p < nclaims; p += NT) {
           unsigned long long v = ord_get(S, sh, P, ord_lds, ob, p);
