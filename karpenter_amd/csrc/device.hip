@@ -329,7 +329,7 @@ void launch_sim_gather(const DevProblem& P, const SimBatch& B, const SimState* s
 }
 // k_sim_init -> k_simulate -> k_sim_gather of one batch back to back: four events, ONE host synchronisation (the three
 // launch groups above each wait for their own kernel)
-void launch_sim_round(const DevProblem& P, const SimBatch& B, const SimState* sims, int block, float ms[3]) {
+void launch_sim_round(const DevProblem& P, const SimBatch& B, const SimState* sims, int block, float ms[3], void* res_host, const void* res_dev, size_t res_bytes) {
   ms[0] = ms[1] = ms[2] = 0;
   if (!B.nsims) return;
   EventScope<4> es("kg consolidation round (k_sim_init, k_simulate, k_sim_gather)");
@@ -342,7 +342,10 @@ void launch_sim_round(const DevProblem& P, const SimBatch& B, const SimState* si
   hipLaunchKernelGGL(k_sim_gather, dim3(B.nsims), dim3(64), 0, t_stream, P, B, sims);
   ck(hipEventRecord(ev[3], t_stream), "record");
   ck(hipGetLastError(), "consolidation round launch");
-  ck(hipEventSynchronize(ev[3]), "kernel execution");
+  if (res_host && res_bytes) {  // (the outcomes ride behind the gather: one wait for kernels and copy)
+    ck(hipMemcpyAsync(res_host, res_dev, res_bytes, hipMemcpyDeviceToHost, t_stream), "hipMemcpy D2H");
+    ck(hipStreamSynchronize(t_stream), "kernel execution");
+  } else ck(hipEventSynchronize(ev[3]), "kernel execution");
   for (int i = 0; i < 3; ++i) ck(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]), "elapsed");
 }
 const char* backend() { return "hip-gfx950"; }

@@ -104,10 +104,11 @@ void launch_sim_gather(const DevProblem& P, const SimBatch& B, const SimState* s
   for (int i = 0; i < B.nsims; ++i) sim_gather(P, B, sims[i], (uint32_t)i);
   *ms = 0;
 }
-void launch_sim_round(const DevProblem& P, const SimBatch& B, const SimState* sims, int block, float ms[3]) {
+void launch_sim_round(const DevProblem& P, const SimBatch& B, const SimState* sims, int block, float ms[3], void* res_host, const void* res_dev, size_t res_bytes) {
   launch_sim_init(P, B, &ms[0]);
   launch_solve(P, sims, B.nsims, B.nqueue, block, &ms[1], true);
   launch_sim_gather(P, B, sims, &ms[2]);
+  if (res_host && res_bytes) d2h(res_host, res_dev, res_bytes);
 }
 void launch_probes(const DevProblem&, const SimState*, void*) {}
 void range_push(const char*) {}

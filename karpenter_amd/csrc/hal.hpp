@@ -50,7 +50,9 @@ void launch_truncate(const DevProblem& P, const SimState* sims, const TruncArgs&
 void launch_sim_init(const DevProblem& P, const SimBatch& B, float* ms);
 void launch_sim_gather(const DevProblem& P, const SimBatch& B, const SimState* sims, float* ms);
 // the three of a batch back to back with one host synchronisation; ms = {init, simulate, gather}
-void launch_sim_round(const DevProblem& P, const SimBatch& B, const SimState* sims, int block, float ms[3]);
+// ... and the batch's outcomes copied to `res_host` (page-locked) behind k_sim_gather, before that one synchronisation
+void launch_sim_round(const DevProblem& P, const SimBatch& B, const SimState* sims, int block, float ms[3], void* res_host = nullptr, const void* res_dev = nullptr,
+                      size_t res_bytes = 0);
 // debug_probes.hip: the latency micro-probes (debug timers only)
 void launch_probes(const DevProblem& P, const SimState* sims, void* stream);
 // roctx ranges around the host phases of an entry point (the launch groups above carry their own)

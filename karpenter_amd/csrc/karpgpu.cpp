@@ -2787,14 +2787,13 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
     B.pod_nonpending = (const uint8_t*)tp(PL.o_np); B.node_uninit = (const uint64_t*)tp(PL.o_un); B.nsims = (int)nb;
     const SimState* sims_dev = (const SimState*)rp_(PL.o_sims) + b0;
     float ms3[3] = {0, 0, 0};
-    hal::launch_sim_round(C->dp, B, sims_dev, ctx->sim_block_threads, ms3);
+    hal::launch_sim_round(C->dp, B, sims_dev, ctx->sim_block_threads, ms3, results + b0, (const SimResult*)rp_(PL.o_res) + b0, nb * sizeof(SimResult));
     const float ms_i = ms3[0], ms_s = ms3[1], ms_g = ms3[2];
     ms_total += ms_i + ms_s + ms_g;
     ms_init += ms_i; ms_sim += ms_s; ms_gather += ms_g;
     ctx->stats.kernel_launches += 3;
     ctx->stats.solves += nb;
   }
-  hal::d2h(results, rp_(PL.o_res), live.size() * sizeof(SimResult));
   if (device_ms) *device_ms = ms_total;
   if (C->dp.stats & 8) {
     // debug (kg_set_collect_stats bit 5): per-wave cycle accounting of the batch's simulations, summed
