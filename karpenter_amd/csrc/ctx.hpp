@@ -39,11 +39,32 @@ struct kg_ctx {
     if (pool.size() >= 6) { kg::hal::dfree(pool.front().ptr); pool.erase(pool.begin()); }
     pool.push_back(kg::DeviceBuffer{p, bytes});
   }
+  // Page-locked staging for a call's uploads (problem image, state image, descriptors): copied here and sent without waiting,
+  // ordered on the context's stream before the kernels that read them.  One call at a time uses it (under `mu`); a call starts
+  // at offset 0 after the previous one's last wait.  `may_grow` false (kg_solve_noalloc): only what is already there.
+  void* stage = nullptr;
+  size_t stage_cap = 0, stage_off = 0;
+  void upload(void* dst, const void* src, size_t bytes, bool may_grow) {
+    if (!bytes) return;
+    const size_t need = (stage_off + bytes + 255) & ~size_t(255);
+    if (need > stage_cap) {
+      if (!may_grow) { kg::hal::h2d(dst, src, bytes); return; }
+      kg::hal::sync();  // (copies out of the old buffer may still be on their way)
+      kg::hal::host_pinned_free(stage);
+      stage_cap = std::max(need * 2, (size_t)4 << 20);
+      stage = kg::hal::host_pinned(stage_cap);
+      stage_off = 0;
+    }
+    std::memcpy((uint8_t*)stage + stage_off, src, bytes);
+    kg::hal::h2d_async(dst, (uint8_t*)stage + stage_off, bytes);
+    stage_off = (stage_off + bytes + 255) & ~size_t(255);
+  }
   // merged views of the catalog sets recent solves named (at most 2 kept); owned by the context
   std::vector<kg_catalog*> merged;
   uint64_t merged_clock = 0;
   ~kg_ctx() {
     for (auto& b : pool) kg::hal::dfree(b.ptr);
+    kg::hal::host_pinned_free(stage);
     for (auto* m : merged) { kg::hal::dfree(m->tab.dev.ptr); delete m; }
   }
   uint32_t kHostname, kZone, kCT, kZid, kNodePool, kInstanceType;

@@ -204,6 +204,10 @@ void h2d(void* dst, const void* src, size_t bytes) {
   ck(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, t_stream), "hipMemcpy H2D");
   ck(hipStreamSynchronize(t_stream), "hipMemcpy H2D");
 }
+void h2d_async(void* dst, const void* src_pinned, size_t bytes) {
+  if (bytes) ck(hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, t_stream), "hipMemcpy H2D (page-locked)");
+}
+void sync() { ck(hipStreamSynchronize(t_stream), "hipStreamSynchronize"); }
 void d2h(void* dst, const void* src, size_t bytes) {
   if (!bytes) return;
   ck(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, t_stream), "hipMemcpy D2H");

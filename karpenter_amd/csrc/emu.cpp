@@ -27,6 +27,8 @@ void dfree(void* p) { std::free(p); }
 void* host_pinned(size_t bytes) { return std::malloc(bytes ? bytes : 8); }
 void host_pinned_free(void* p) { std::free(p); }
 void h2d(void* dst, const void* src, size_t bytes) { if (bytes) std::memcpy(dst, src, bytes); }
+void h2d_async(void* dst, const void* src_pinned, size_t bytes) { if (bytes) std::memcpy(dst, src_pinned, bytes); }
+void sync() {}
 void d2h(void* dst, const void* src, size_t bytes) { if (bytes) std::memcpy(dst, src, bytes); }
 void d2h_rows(void* dst, const void* src, size_t width, size_t spitch, size_t rows) {
   for (size_t r = 0; r < rows; ++r) std::memcpy((char*)dst + r * width, (const char*)src + r * spitch, width);

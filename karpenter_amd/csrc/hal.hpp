@@ -32,6 +32,10 @@ void host_pinned_free(void* p);
 void dfree(void* p);
 void h2d(void* dst, const void* src, size_t bytes);
 void d2h(void* dst, const void* src, size_t bytes);
+// from page-locked host memory, NOT waited for: ordered before whatever the stream runs next; the source must stay untouched
+// until the stream has been synchronised (sync(), or any of the waiting calls above)
+void h2d_async(void* dst, const void* src_pinned, size_t bytes);
+void sync();
 // `rows` rows of `width` bytes, `spitch` bytes apart on the device, packed back to back on the host: one strided copy
 void d2h_rows(void* dst, const void* src, size_t width, size_t spitch, size_t rows);
 void dzero(void* dst, size_t bytes);

@@ -1433,12 +1433,15 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   const size_t o_amask = A.reserve_tail((size_t)std::max(E, 1u) * TW * 8), o_podmask = A.reserve_tail((size_t)std::max(NV, 1) * TW * 8),
                o_pctx = A.reserve_tail((size_t)std::max(NV, 1) * sizeof(PodCtx)), o_atab = A.reserve_tail(5 * KG_MAXR * 4),
                o_nlab = A.reserve_tail((size_t)std::max(S, 1) * NW * 8);
+  KG_PROF("pack: upload");
   C.prob_dev.bytes = A.total();
   C.fixed = in.fixed != nullptr;
   if (in.fixed) { C.prob_dev.ptr = in.fixed->take(C.prob_dev.bytes, "problem tables"); C.prob_cap = C.prob_dev.bytes; }
   else C.prob_dev.ptr = ctx->pool_take(C.prob_dev.bytes, &C.prob_cap);
-  hal::h2d(C.prob_dev.ptr, A.bytes.data(), A.bytes.size());
+  ctx->stage_off = 0;  // (the previous call on this context ended with a wait: nothing of it is on its way any more)
+  ctx->upload(C.prob_dev.ptr, A.bytes.data(), A.bytes.size(), !in.fixed);
   hal::dzero((uint8_t*)C.prob_dev.ptr + A.bytes.size(), C.prob_dev.bytes - A.bytes.size());
+  KG_PROF("pack: descriptor");
   auto dptr = [&](size_t off) { return (uint8_t*)C.prob_dev.ptr + off; };
   auto cptr = [&](size_t off) { return (uint8_t*)CT.dev.ptr + off; };
   DevProblem& D = C.dp;
@@ -1470,7 +1473,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
     atab[0 * KG_MAXR + r] = toff[g]; atab[1 * KG_MAXR + r] = tn[g]; atab[2 * KG_MAXR + r] = coff[g]; atab[3 * KG_MAXR + r] = cn[g]; atab[4 * KG_MAXR + r] = g;
   }
   D.atab = (const uint32_t*)dptr(o_atab);
-  hal::h2d(dptr(o_atab), atab.data(), atab.size() * 4);
+  ctx->upload(dptr(o_atab), atab.data(), atab.size() * 4, !in.fixed);
   D.R = R; D.Ka = Ka; D.Wa = C.Wa; D.T = T; D.TW = TW; D.NP = NP; D.N = N; D.NW = NW; D.P = P; D.S = S; D.G = G; D.GH = GH; D.H = H;
   D.Cmax = Cmax; D.nspec = nspec; D.NL = (int)lists.size();
   D.slot_zone = spec_of_key(ctx->kZone); D.slot_ct = spec_of_key(ctx->kCT); D.slot_zid = spec_of_key(ctx->kZid);
@@ -1571,7 +1574,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   C.state_dev.bytes = C.state_bytes + tail;
   if (in.fixed) { C.state_dev.ptr = in.fixed->take(C.state_dev.bytes, "solve state"); C.state_cap = C.state_dev.bytes; }
   else C.state_dev.ptr = ctx->pool_take(C.state_dev.bytes, &C.state_cap);
-  hal::h2d(C.state_dev.ptr, C.state_image.data(), C.state_init_bytes);
+  ctx->upload(C.state_dev.ptr, C.state_image.data(), C.state_init_bytes, !in.fixed);
   hal::dzero((uint8_t*)C.state_dev.ptr + C.state_init_bytes, C.state_bytes - C.state_init_bytes);
   C.sim = sim_at(C, (uint8_t*)C.state_dev.ptr);
   if (C.trunc_claims) {
@@ -1584,7 +1587,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   C.sims_dev.bytes = sizeof(SimState);
   if (in.fixed) { C.sims_dev.ptr = in.fixed->take(sizeof(SimState), "state descriptor"); C.sims_cap = sizeof(SimState); }
   else C.sims_dev.ptr = ctx->pool_take(sizeof(SimState), &C.sims_cap);
-  hal::h2d(C.sims_dev.ptr, &St, sizeof(SimState));
+  ctx->upload(C.sims_dev.ptr, &St, sizeof(SimState), !in.fixed);
   KG_PROF("end");
   return Cp;
 }
