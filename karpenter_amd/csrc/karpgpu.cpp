@@ -2407,12 +2407,20 @@ struct ValidateOut {
 // the price logic on what comes back.  (Round 1 rebuilt all of it in every call on every rank: 6 of 8 ms on C4.)
 namespace {
 struct Hasher {
-  uint64_t h = 1469598103934665603ull;
+  // two independent 64-bit mixes of the same bytes and their count: a plan is reused only when all three agree (and its
+  // candidate list compares equal) -- no single hash decides alone
+  uint64_t h = 1469598103934665603ull, h2 = 0x9E3779B97F4A7C15ull, total = 0;
   void bytes(const void* p, size_t n) {
     const uint8_t* b = (const uint8_t*)p;
     size_t i = 0;
-    for (; i + 8 <= n; i += 8) { uint64_t w; std::memcpy(&w, b + i, 8); h = (h ^ w) * 1099511628211ull; h ^= h >> 29; }
-    for (; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    total += n;
+    for (; i + 8 <= n; i += 8) {
+      uint64_t w;
+      std::memcpy(&w, b + i, 8);
+      h = (h ^ w) * 1099511628211ull; h ^= h >> 29;
+      h2 = (h2 + w) * 0xD6E8FEB86659FD93ull; h2 ^= h2 >> 32;
+    }
+    for (; i < n; ++i) { h = (h ^ b[i]) * 1099511628211ull; h2 = (h2 + b[i]) * 0xD6E8FEB86659FD93ull; h2 ^= h2 >> 32; }
   }
   void u64(uint64_t v) { bytes(&v, 8); }
   template <class T> void arr(const T* p, size_t n) { u64(n); if (n && p) bytes(p, n * sizeof(T)); }
@@ -2427,7 +2435,7 @@ struct Hasher {
 
 struct ConsUnit { uint32_t id, pod_lo, pod_hi; bool skip; };
 struct kg_cons_plan {
-  uint64_t key = 0;
+  uint64_t key = 0, key2 = 0, key_bytes = 0;  // Hasher::h / h2 / total of what the plan was built from
   bool multi = false;
   uint32_t n = 0, n_used = 0, n_shared = 0;
   std::vector<int32_t> candidates;
@@ -2699,7 +2707,10 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
       H.pools(pending->pools); H.arr(pending->pods, pending->n_pods); H.arr(pending->weighted_terms, pending->n_weighted_terms); H.arr(pending->spreads, pending->n_spreads);
       H.arr(pending->affinity_terms, pending->n_affinity_terms); H.arr(pending->host_ports, pending->n_host_ports);
     }
-    for (auto* p : cluster->plans) if (p->key == H.h && p->multi == multi) PLp = p;
+    for (auto* p : cluster->plans)
+      if (p->key == H.h && p->key2 == H.h2 && p->key_bytes == H.total && p->multi == multi && p->n == n && p->candidates.size() <= n &&
+          (p->candidates.empty() || std::memcmp(p->candidates.data(), cands->candidates, p->candidates.size() * sizeof(int32_t)) == 0))
+        PLp = p;  // (the plan keeps the candidates it uses: all of them, or the first 101 of a multi-node round)
     if (PLp) ctx->stats.cons_plan_hits += 1;
     else {
       ctx->stats.cons_plans_built += 1;
@@ -2710,7 +2721,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
         cluster->plans.erase(cluster->plans.begin() + old);
       }
       auto np = build_cons_plan(ctx, cat, cluster, pending, nodepools, cands, multi, false);
-      np->key = H.h;
+      np->key = H.h; np->key2 = H.h2; np->key_bytes = H.total;
       PLp = np.release();
       cluster->plans.push_back(PLp);
     }
