@@ -1926,8 +1926,9 @@ int32_t kg_cluster_upload(kg_ctx* ctx, const kg_cluster_desc* desc, kg_cluster**
   parse_pods(ctx, &desc->pods, &cl->bound, true);
   KG_PROF("upload: volume limits");
   for (auto& bp : cl->bound.pods) check(bp.node >= 0 && bp.node < (int)cl->nodes.size(), "bound pod node index");
-  // volume limits: what the node can still attach per CSI driver = CSINode count - volumes of the pods bound to it (clamped at
-  // 0: a node over its limit takes no more volumes but still takes pods without any)
+  // volume limits: what the node can still attach per CSI driver = CSINode count - volumes of the pods bound to it.  A node
+  // already OVER a driver's limit refuses every pod, with or without volumes: VolumeUsage.ExceedsLimits walks the union of the
+  // node's and the pod's volumes over all drivers (a negative availability marks the node infeasible in compile_problem)
   for (uint32_t i = 0; i < desc->n_nodes; ++i) {
     if (desc->nodes[i].volume_limits.count == 0) continue;
     for (auto& q : kgdesc::quantities(p, desc->nodes[i].volume_limits)) {
@@ -1936,7 +1937,7 @@ int32_t kg_cluster_upload(kg_ctx* ctx, const kg_cluster_desc* desc, kg_cluster**
       for (auto& bp : cl->bound.pods)
         if (bp.node == (int)i)
           for (uint32_t k = 0; k < bp.rq_n; ++k) if (cl->bound.rq[bp.rq_off + k].first == rid) left -= cl->bound.rq[bp.rq_off + k].second;
-      cl->nodes[i].available.push_back({rid, std::max<int64_t>(left, 0)});
+      cl->nodes[i].available.push_back({rid, left});  // (negative = over its limit: the node takes no pod at all, see below)
       cl->nodes[i].volume_limited.push_back(rid);
     }
   }

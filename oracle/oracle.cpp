@@ -791,14 +791,14 @@ struct ExistingNode {
   // scheduling.VolumeUsage: volumes in use per CSI driver, and the CSINode's attachable count (drivers without one: unlimited)
   std::map<int, std::set<int>> volumes;
   std::map<int, int64_t> volumeLimits;
+  // (PARITY UNPINNED: the file is not in the reference checkout.  Restated as upstream's v.volumes.Union(vols) walk: every
+  // driver of the node OR the pod is checked, so a node already over a driver's limit refuses pods without volumes too.)
   bool ExceedsLimits(const Pod& pod) const {
-    for (auto& kv : pod.volumes) {
+    std::map<int, std::set<int>> u = volumes;
+    for (auto& kv : pod.volumes) u[kv.first].insert(kv.second.begin(), kv.second.end());
+    for (auto& kv : u) {
       auto lim = volumeLimits.find(kv.first);
-      if (lim == volumeLimits.end()) continue;
-      std::set<int> u = kv.second;
-      auto have = volumes.find(kv.first);
-      if (have != volumes.end()) u.insert(have->second.begin(), have->second.end());
-      if ((int64_t)u.size() > lim->second) return true;
+      if (lim != volumeLimits.end() && (int64_t)kv.second.size() > lim->second) return true;
     }
     return false;
   }

@@ -15,6 +15,15 @@ def check_volume_limits(L):
     free = Problem(prob.types, prob.raw_pods, prob.raw_nodepools, nodes=free_nodes, bound=prob.raw_bound).run_oracle().decode()
     on_nodes = lambda r: sum(1 for k, _ in r["pods"] if k == abi.POD_EXISTING_NODE)
     assert on_nodes(free) > on_nodes(want) > 0
+    # a node already over a driver's limit takes no pod at all, with or without volumes (ExceedsLimits walks the union of the
+    # node's and the pod's volumes over every driver -- PARITY UNPINNED, oracle/oracle.cpp)
+    held = {}
+    for p in prob.raw_bound:
+        for drv, vol in p.get("volumes", []):
+            held.setdefault((p["node"], drv), set()).add(vol)
+    over = {n for (n, drv), vols in held.items() if drv in (prob.raw_nodes[n].get("volume_limits") or {}) and len(vols) > prob.raw_nodes[n]["volume_limits"][drv]}
+    assert over, "the scenario holds nodes over their limit"
+    assert not any(k == abi.POD_EXISTING_NODE and i in over for k, i in want["pods"])
     # internal bookkeeping stays inside: no claim reports a volume resource
     assert all(not any("volumes" in k for k in c["requests"]) for c in want["claims"])
     assert all(not any("volumes" in k for k in c["requests"]) for c in prob.run_library(L).decode()["claims"])
