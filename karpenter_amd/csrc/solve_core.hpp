@@ -1546,15 +1546,15 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
           q2.x = q2.y = q2.z = q2.w = 0;
           if (pf_word) cword = ctx_word_load(P, tid, qe_next.x, qe_next.y);
           if (want_pf && want_q2 && tid == NT - 1) q2 = ((const KG_GLOBAL uint4*)S.queue)[q2_pos];
-          uint64_t we[KG_NSCAN], wt[KG_NSCAN], wl[KG_NSCAN], wp[KG_NSCAN];
+          uint64_t w_exc[KG_NSCAN], w_tol[KG_NSCAN], w_lab[KG_NSCAN], w_prt[KG_NSCAN];
           int64_t nf[KG_NSCAN][KG_MAXR];
 #pragma unroll
           for (int j = 0; j < KG_NSCAN; ++j) {
             const uint32_t n = base + (uint32_t)j * NT + tid, nn = n < (uint32_t)P.N ? n : 0u, wi = nn >> 6;  // (every load unconditional)
-            we[j] = S.excl[wi];
-            wt[j] = P.ntol[(size_t)v.tolset * P.NW + wi];
-            wl[j] = P.nlab[(size_t)v.rs * P.NW + wi];
-            wp[j] = P.has_ports ? S.nports[nn] : 0ull;
+            w_exc[j] = S.excl[wi];
+            w_tol[j] = P.ntol[(size_t)v.tolset * P.NW + wi];
+            w_lab[j] = P.nlab[(size_t)v.rs * P.NW + wi];
+            w_prt[j] = P.has_ports ? S.nports[nn] : 0ull;
 #pragma unroll
             for (int r = 0; r < KG_MAXR; ++r) {
               nf[j][r] = 0;
@@ -1565,7 +1565,7 @@ KG_HD void solve_block(const DevProblem& P, const SimState& S, Shared& sh, uint3
 #pragma unroll
           for (int j = KG_NSCAN - 1; j >= 0; --j) {
             const uint32_t n = base + (uint32_t)j * NT + tid, bi = n & 63;
-            bool ok = n < (uint32_t)P.N && !((we[j] >> bi) & 1) && ((wt[j] >> bi) & 1) && ((wl[j] >> bi) & 1) && !(wp[j] & pc.vc.hp_conf);
+            bool ok = n < (uint32_t)P.N && !((w_exc[j] >> bi) & 1) && ((w_tol[j] >> bi) & 1) && ((w_lab[j] >> bi) & 1) && !(w_prt[j] & pc.vc.hp_conf);
 #pragma unroll
             for (int r = 0; r < KG_MAXR; ++r) ok = ok && (!((need >> r) & 1) || pc.preq[r] <= nf[j][r]);
             mine = ok ? n : mine;
