@@ -138,9 +138,14 @@ def solve_leg(L, hcat, prob, steps, warmup, barrier=None, want_alg=True):
 def cons_leg(args, L, hcat, cl, order, multi, world, device, barrier, dist, torch, default_workload):
     """One consolidation leg (single- or multi-node) on one cluster descriptor: warm rounds on a resident snapshot, then
     cold rounds (a new snapshot each: kg_cluster_upload + plan build + round)."""
+    import numpy as np
     from karpenter_amd import abi, distributed, workloads as wl
     pend, nps = abi.build_pods([]), abi.build_nodepools([wl.default_nodepool()], wl.WELL_KNOWN_LABELS)
     hcl = L.cluster_upload(cl)
+    # the candidate descriptor of this rank's shard and its record buffer: built once, as a controller that polls keeps them
+    rank = dist.get_rank() if world > 1 else 0
+    cd = abi.build_candidates(order, shard=rank, n_shards=world)
+    recs = np.zeros(max(len(order), 1), abi.CANDIDATE_RECORD)
     alg = 0.0
     if not args.no_alg_bytes:  # (one untimed round with the visit counters on)
         L.set_collect_stats(True)
@@ -156,7 +161,7 @@ def cons_leg(args, L, hcat, cl, order, multi, world, device, barrier, dist, torc
     dms, kms, ims, tim = [], [], [], []
     dec = info = None
     for _ in range(args.steps):
-        dec, info = distributed.consolidate(L, hcat, hcl, pend, nps, order, multi, device=device, want_info=True)
+        dec, info = distributed.consolidate(L, hcat, hcl, pend, nps, order, multi, device=device, want_info=True, cands=cd, out=recs, want_hist=False)
         st = L.stats()
         dms.append(info["device_ms"])
         kms.append(st.cons_simulate_ms)
@@ -164,6 +169,7 @@ def cons_leg(args, L, hcat, cl, order, multi, world, device, barrier, dist, torc
         tim.append(info)
     barrier()
     dt = time.perf_counter() - t0
+    info["decisions"] = distributed.consolidate(L, hcat, hcl, pend, nps, order, multi, device=device, want_info=True, cands=cd, out=recs)[1]["decisions"]  # (untimed: the verdict histogram)
     L.dll.kg_cluster_free(hcl)
     # cold rounds: what a controller pays when the cluster changed since its last poll
     cold_steps = 0 if args.no_cold else max(1, min(args.steps, 5))
@@ -175,7 +181,7 @@ def cons_leg(args, L, hcat, cl, order, multi, world, device, barrier, dist, torc
             u0 = time.perf_counter()
             h2 = L.cluster_upload(cl)
             cup.append((time.perf_counter() - u0) * 1e3)
-            distributed.consolidate(L, hcat, h2, pend, nps, order, multi, device=device)
+            distributed.consolidate(L, hcat, h2, pend, nps, order, multi, device=device, cands=cd, out=recs)
             L.dll.kg_cluster_free(h2)
         barrier()
         cdt = time.perf_counter() - c0

@@ -65,15 +65,16 @@ def gather_records(local, n_units_total, device):
     return np.concatenate(parts)
 
 
-def consolidate(L, hcat, hcl, pending, nodepools, order, multi, spot_to_spot=False, device="cpu", want_info=False):
+def consolidate(L, hcat, hcl, pending, nodepools, order, multi, spot_to_spot=False, device="cpu", want_info=False, cands=None, out=None, want_hist=True):
     """-> (decision dict on every rank, records evaluated by this rank, device_ms of this rank); with want_info:
     (decision dict, info) where info holds this rank's wall time per part (records_ms = the kg_consolidate_* call,
     gather_ms, select_ms), device_ms, n_local and the verdict histogram of the gathered records [no-op, delete, replace]."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    cd = abi.build_candidates(order, spot_to_spot=spot_to_spot, shard=rank, n_shards=world)
+    # (`cands`: this rank's candidate descriptor, `out`: its record buffer -- built once by a caller that polls, else per call)
+    cd = cands if cands is not None else abi.build_candidates(order, spot_to_spot=spot_to_spot, shard=rank, n_shards=world)
     t0 = time.perf_counter()
-    local, dms = L.consolidate_records([hcat], hcl, pending, nodepools, cd, multi)
+    local, dms = L.consolidate_records([hcat], hcl, pending, nodepools, cd, multi, out=out)
     t1 = time.perf_counter()
     n_units = (min(len(order), 101) - 1 if multi else len(order)) if len(order) else 0
     allrec = gather_records(local, max(n_units, 1), device)
@@ -82,6 +83,6 @@ def consolidate(L, hcat, hcl, pending, nodepools, order, multi, spot_to_spot=Fal
     t3 = time.perf_counter()
     if not want_info:
         return dec, len(local), dms
-    hist = [int((allrec["decision"] == k).sum()) for k in (0, 1, 2)] if len(allrec) else [0, 0, 0]
+    hist = ([int((allrec["decision"] == k).sum()) for k in (0, 1, 2)] if len(allrec) else [0, 0, 0]) if want_hist else None
     return dec, {"records_ms": (t1 - t0) * 1e3, "gather_ms": (t2 - t1) * 1e3, "select_ms": (t3 - t2) * 1e3, "device_ms": dms, "n_local": len(local),
                  "decisions": hist}

@@ -170,11 +170,12 @@ class Library:
                                       C.addressof(rb.res)))
         return rb
 
-    def consolidate_records(self, catalogs, cluster, pending, nodepools, cands, multi):
-        """One SimulateScheduling + computeConsolidation per unit of the shard -> (records, device_ms)."""
+    def consolidate_records(self, catalogs, cluster, pending, nodepools, cands, multi, out=None):
+        """One SimulateScheduling + computeConsolidation per unit of the shard -> (records, device_ms).
+        `out`: the caller's record buffer (>= n_candidates rows of abi.CANDIDATE_RECORD), as a controller that polls would keep."""
         import numpy as np
         arr = (C.c_void_p * len(catalogs))(*catalogs)
-        recs = np.zeros(max(cands.desc.n_candidates, 1), abi.CANDIDATE_RECORD)
+        recs = out if out is not None and out.shape[0] >= max(cands.desc.n_candidates, 1) else np.zeros(max(cands.desc.n_candidates, 1), abi.CANDIDATE_RECORD)
         k, ms = C.c_uint32(0), C.c_double(0)
         fn = self.dll.kg_consolidate_multi if multi else self.dll.kg_consolidate_single
         self._check(fn(self.ctx, arr, len(catalogs), cluster, C.addressof(pending.desc), C.addressof(nodepools.desc), C.addressof(cands.desc),
