@@ -2752,6 +2752,8 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
     PL.shard = cands->shard; PL.n_shards = shards;
     PL.live.clear();
     for (uint32_t k : mine) if (!units[k].skip) PL.live.push_back(k);
+    // longest simulations first (the hardware hands workgroups out in launch order: the long ones must not start last)
+    std::stable_sort(PL.live.begin(), PL.live.end(), [&](uint32_t a, uint32_t b) { return units[a].pod_hi - units[a].pod_lo > units[b].pod_hi - units[b].pod_lo; });
     hal::dfree(PL.arena.ptr); hal::dfree(PL.run.ptr); hal::host_pinned_free(PL.results_host);
     PL.arena = DeviceBuffer(); PL.run = DeviceBuffer(); PL.results_host = nullptr;
     if (!PL.live.empty()) {
