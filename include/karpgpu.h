@@ -385,6 +385,7 @@ typedef struct {
    * Queue order), and over them: pods committed straight from their speculative evaluation, window claims evaluated again at
    * a pod's turn, pods rescanned at their turn (their claim took another pod meanwhile) */
   uint64_t spec_solves, spec_fast_commits, spec_challengers, spec_rescans;
+  uint64_t spec_fallbacks;   /* speculative solves whose waves gave up waiting and that were run again on the single-wave kernel */
 } kg_stats;
 
 typedef struct kg_ctx kg_ctx;
@@ -404,7 +405,8 @@ int32_t kg_stats_get(kg_ctx* ctx, kg_stats* out);
  * debugging aids: 2 = phase timers to stderr, 4 / 8 = 1024 / 512 threads for the workgroup kernel, 16 = never use the
  * wave-local / single-wave paths, 32 = per-wave cycle accounting to stderr, 64 = never use the speculative multi-wave
  * kernel (such batches then run on the single-wave kernel), 128 = the speculative kernel evaluates every pod again at its
- * turn (no verdict of the speculative evaluation is used).  Consolidation rounds honour 2 (every simulation
+ * turn (no verdict of the speculative evaluation is used), 256 = treat every speculative solve as one whose waves gave up
+ * waiting (exercises the automatic fallback to the single-wave kernel, kg_stats.spec_fallbacks).  Consolidation rounds honour 2 (every simulation
  * leaves time stamps; staging time and a per-pod fit of the batch go to stderr) and 32 (a debug instantiation of the batch
  * kernel, cycles per phase and wave summed over the batch); set them before the first round on a snapshot (plans are cached). */
 int32_t kg_set_collect_stats(kg_ctx* ctx, int32_t enabled);

@@ -156,7 +156,8 @@ class Stats(C.Structure):
                 ("cons_simulations", C.c_uint64), ("cons_algorithmic_bytes", C.c_double), ("cons_prepass_ms", C.c_double), ("cons_sim_init_ms", C.c_double),
                 ("cons_simulate_ms", C.c_double), ("cons_gather_ms", C.c_double), ("cons_state_bytes_per_simulation", C.c_uint64),
                 ("cons_plans_built", C.c_uint64), ("cons_plan_hits", C.c_uint64),
-                ("spec_solves", C.c_uint64), ("spec_fast_commits", C.c_uint64), ("spec_challengers", C.c_uint64), ("spec_rescans", C.c_uint64)]
+                ("spec_solves", C.c_uint64), ("spec_fast_commits", C.c_uint64), ("spec_challengers", C.c_uint64), ("spec_rescans", C.c_uint64),
+                ("spec_fallbacks", C.c_uint64)]
 
 
 def _ptr(a):

@@ -15,6 +15,7 @@ struct kg_ctx {
   bool wave_timers = false;   // debug: per-wave work / barrier-wait cycles per phase kind (kg_set_collect_stats bit 5)
   bool no_fast_path = false;  // debug: keep every placement on the workgroup-wide evaluation (kg_set_collect_stats bit 4)
   bool no_spec = false;       // debug: never the speculative multi-wave kernel (kg_set_collect_stats bit 6)
+  bool spec_fake_fail = false;  // debug: treat every speculative solve as one whose waves gave up (exercises the fallback; kg_set_collect_stats bit 8)
   bool spec_serial = false;   // debug: the speculative kernel evaluates every pod at its turn (kg_set_collect_stats bit 7)
   int spec_waves = 4;         // waves (= pods in flight) of the speculative kernel: 2, 4, 6 or 8 (KG_SPEC_WAVES overrides, for measurements)
   int sim_block_threads = 256;  // workgroup size of k_solve for consolidation batches (one workgroup per simulation)

@@ -296,3 +296,19 @@ def test_threaded_abi_on_hip_streams():
     r = subprocess.run([exe, "3"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=150)
     out = r.stdout.decode("utf-8", "replace")
     assert r.returncode == 0 and "abi_threads ok" in out, out[-4000:]
+
+
+def test_speculative_kernel_falls_back(L):
+    """A speculative solve whose waves gave up waiting is run again on the single-wave kernel inside the same call (debug
+    bit 256 pretends every speculative solve ended that way): same results, kg_stats.spec_fallbacks counts it."""
+    zones, types = catalog776()
+    prob = Problem(types, wl.mixed_pods(1500, 5, zones, families(types)), [wl.default_nodepool()])
+    ro = prob.run_oracle()
+    try:
+        L.set_collect_stats(256)
+        f0, s0 = L.stats().spec_fallbacks, L.stats().spec_solves
+        rg = prob.run_library(L)
+        assert L.stats().spec_solves == s0 + 1 and L.stats().spec_fallbacks == f0 + 1
+    finally:
+        L.set_collect_stats(True)
+    assert diff_results(ro.decode(), rg.decode()) == ""
