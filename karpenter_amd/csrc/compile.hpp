@@ -8,6 +8,7 @@
 // their initial domain counts.
 #pragma once
 #include <array>
+#include <future>
 #include <set>
 
 #include "ctx.hpp"
@@ -81,7 +82,11 @@ struct kg_cluster {
   kg_ctx* ctx;
   std::vector<kg::CNode> nodes;
   kg::ParsedPods bound;
-  mutable std::vector<uint32_t> bound_rank;  // place of every bound pod in the Queue order among the bound pods (computed at first use)
+  // place of every bound pod in the Queue order among the bound pods: worked out by `rank_job` (started at the end of
+  // kg_cluster_upload for large snapshots, reads `bound` only) or at first use; wait_rank() before reading it or freeing the cluster
+  std::vector<uint32_t> bound_rank;
+  std::future<void> rank_job;
+  void wait_rank() { if (rank_job.valid()) rank_job.get(); }
   std::vector<struct kg_cons_plan*> plans;    // consolidation plans built over this snapshot (karpgpu.cpp), least recently used dropped beyond 4
   uint64_t plan_clock = 0;
 };

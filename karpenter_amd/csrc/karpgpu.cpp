@@ -6,12 +6,26 @@
 #include <unordered_set>
 
 #include "compile.hpp"
+#include "host_threads.hpp"
 
 using namespace kg;
 void kg_cluster_drop_plans(kg_cluster* cl);
 using kgdesc::check;
 
 namespace kg {
+// KG_HOST_PROF=1: wall time of every section of the host's longer functions to stderr (host-side tuning aid)
+struct HostProf {
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  const char* name = "start";
+  bool on = getenv("KG_HOST_PROF") != nullptr;
+  void mark(const char* next) {
+    if (!on) return;
+    auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[kg host] %-42s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n; name = next;
+  }
+};
+#define KG_PROF(x) prof_.mark(x)
 
 // ------------------------------------------------------------------ selectors
 bool PSel::matches(const std::vector<std::pair<uint32_t, uint32_t>>& labels) const {
@@ -105,137 +119,230 @@ std::vector<PTerm> parse_terms(kg_ctx* ctx, const kg_pods_desc* d, kg_range r) {
   }
   return out;
 }
+// The signature of a pod's scheduling-relevant spec (everything a PodClass holds), as words of descriptor string ids
+static void pod_signature(const kg_pods_desc* d, const kg_pod& q, Sig& sg) {
+  const kg_pools& p = d->pools;
+  sg.clear();
+  sg.u32(q.ns);
+  sg.range_labels(p, q.labels);
+  sg.range_labels(p, q.node_selector);
+  sg.u32(q.required_terms.count);
+  for (auto& r : kgdesc::ranges(p, q.required_terms)) sg.range_reqs(p, r);
+  sg.u32(q.preferred_terms.count);
+  for (auto& w : kgdesc::span(d->weighted_terms, d->n_weighted_terms, q.preferred_terms, "weighted range")) { sg.u32((uint32_t)w.weight); sg.range_reqs(p, w.reqs); }
+  sg.u32(q.tolerations.count);
+  for (auto& t : kgdesc::tolerations(p, q.tolerations)) { sg.u32(t.key); sg.u32(t.value); sg.u32(t.op); sg.u32(t.effect); }
+  sg.u32(q.spreads.count);
+  for (auto& s : kgdesc::span(d->spreads, d->n_spreads, q.spreads, "spread range")) {
+    sg.u32(s.topology_key); sg.u32((uint32_t)s.max_skew); sg.u32((uint32_t)s.min_domains); sg.u32(s.when_unsatisfiable); sg.selector(p, s.selector);
+  }
+  for (kg_range r : {q.affinity_required, q.affinity_preferred, q.anti_affinity_required, q.anti_affinity_preferred}) {
+    sg.u32(r.count);
+    for (auto& t : kgdesc::span(d->affinity_terms, d->n_affinity_terms, r, "affinity range")) {
+      sg.u32(t.topology_key); sg.selector(p, t.selector); sg.u32((uint32_t)t.weight); sg.u32(t.namespaces.count);
+      for (uint32_t v : kgdesc::values(p, t.namespaces)) sg.u32(v);
+    }
+  }
+  sg.u32(q.host_ports.count);
+  for (auto& h : kgdesc::span(d->host_ports, d->n_host_ports, q.host_ports, "host port range")) { sg.u32(h.ip); sg.u32((uint32_t)h.port); sg.u32(h.protocol); }
+}
+
+// The class of pod `q` in vocabulary ids (the only part of pod parsing that interns strings besides resource names)
+static PodClass pod_class(kg_ctx* ctx, const kg_pods_desc* d, const kg_pod& q) {
+  const kg_pools& p = d->pools;
+  PodClass c;
+  c.ns = ctx->lab.id(kgdesc::str(p.strings, q.ns));
+  for (auto& l : kgdesc::labels(p, q.labels)) c.labels.push_back({ctx->lab.id(kgdesc::str(p.strings, l.key)), ctx->lab.id(kgdesc::str(p.strings, l.value))});
+  std::sort(c.labels.begin(), c.labels.end());
+  for (auto& l : kgdesc::labels(p, q.node_selector)) {
+    uint32_t k = ctx->V.key(kgdesc::str(p.strings, l.key));
+    c.node_selector.push_back(hreq_new(ctx->V, k, KG_OP_IN, {ctx->V.val(k, kgdesc::str(p.strings, l.value))}, -1));
+  }
+  for (auto& r : kgdesc::ranges(p, q.required_terms)) c.required.push_back(parse_req_list(ctx, p, r));
+  for (auto& w : kgdesc::span(d->weighted_terms, d->n_weighted_terms, q.preferred_terms, "weighted range"))
+    c.preferred.push_back({w.weight, parse_req_list(ctx, p, w.reqs)});
+  for (auto& t : kgdesc::tolerations(p, q.tolerations))
+    c.tols.push_back({t.key == KG_NONE ? -1 : (int)ctx->lab.id(kgdesc::str(p.strings, t.key)),
+                      t.value == KG_NONE ? ctx->lab.id("") : ctx->lab.id(kgdesc::str(p.strings, t.value)), t.op, t.effect});
+  for (auto& s : kgdesc::span(d->spreads, d->n_spreads, q.spreads, "spread range"))
+    c.spreads.push_back({ctx->V.key(kgdesc::str(p.strings, s.topology_key)), s.max_skew, s.min_domains, s.when_unsatisfiable, parse_selector(ctx, p, s.selector)});
+  c.aff_req = parse_terms(ctx, d, q.affinity_required);
+  c.aff_pref = parse_terms(ctx, d, q.affinity_preferred);
+  c.anti_req = parse_terms(ctx, d, q.anti_affinity_required);
+  c.anti_pref = parse_terms(ctx, d, q.anti_affinity_preferred);
+  c.host_ports = q.host_ports.count != 0;
+  for (auto& h : kgdesc::span(d->host_ports, d->n_host_ports, q.host_ports, "host port range"))
+    c.ports.push_back({h.ip == KG_NONE ? -1 : (int)ctx->lab.id(kgdesc::str(p.strings, h.ip)), h.port, (int)h.protocol});
+  return c;
+}
+
+// pod classes by signature: open addressing on the running hash, the signature words compared on a hit
+struct ClassTable {
+  std::vector<std::vector<uint32_t>> sig;
+  std::vector<uint64_t> hash;
+  uint32_t mask = 1023;
+  std::vector<uint32_t> tab = std::vector<uint32_t>(1024, UINT32_MAX);
+  // the class with this signature, or UINT32_MAX and *slot_out = where add() puts it
+  template <class S>
+  uint32_t find(uint64_t h, const S& same, uint32_t* slot_out) const {
+    uint32_t slot = (uint32_t)(h >> 20) & mask;
+    for (; tab[slot] != UINT32_MAX; slot = (slot + 1) & mask) {
+      const uint32_t k = tab[slot];
+      if (hash[k] == h && same(sig[k])) return k;
+    }
+    *slot_out = slot;
+    return UINT32_MAX;
+  }
+  uint32_t add(uint64_t h, std::vector<uint32_t>&& words, uint32_t slot) {
+    const uint32_t k = (uint32_t)sig.size();
+    sig.push_back(std::move(words));
+    hash.push_back(h);
+    tab[slot] = k;
+    if (sig.size() * 2 > tab.size()) {  // keep the table at most half full
+      mask = mask * 2 + 1;
+      tab.assign(mask + 1, UINT32_MAX);
+      for (uint32_t j = 0; j < sig.size(); ++j) {
+        uint32_t s2 = (uint32_t)(hash[j] >> 20) & mask;
+        while (tab[s2] != UINT32_MAX) s2 = (s2 + 1) & mask;
+        tab[s2] = j;
+      }
+    }
+    return k;
+  }
+};
 }  // namespace
 
+// Three steps.  (1) serial, cheap: resource names -> ids (and the volumes' ids), in pod order.  (2) the pods in contiguous chunks,
+// one thread each, nothing shared but the descriptor and step 1's table: signature, chunk-local class, requests, UID.
+// (3) serial over the chunks' classes in order (= order of first appearance over all pods, what one serial pass numbers them
+// by): the vocabulary is touched here only; then the chunks copy their pools into place.  One chunk below 4 096 pods.
 void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out, bool add_pods_one) {
   if (!d) return;
   const kg_pools& p = d->pools;
-  // pod classes by signature: open addressing on the running hash, the signature bytes compared on a hit
-  std::vector<std::vector<uint32_t>> class_sig;
-  std::vector<uint64_t> class_hash;
-  uint32_t tab_mask = 1023;
-  std::vector<uint32_t> tab(tab_mask + 1, UINT32_MAX);
-  out->pods.reserve(d->n_pods);
-  out->rq.reserve((size_t)d->n_pods * 4);
-  out->uid_pool.reserve((size_t)d->n_pods * 24);
-  std::vector<int32_t> rid_of_str(p.strings.count, -1);
-  std::vector<std::pair<uint32_t, int64_t>> rl;
-  Sig sg;
-  for (uint32_t i = 0; i < d->n_pods; ++i) {
+  const uint32_t n = d->n_pods;
+  const uint32_t NS = p.strings.count;
+  HostProf prof_;
+  KG_PROF("parse_pods: resource ids");
+  std::vector<int32_t> rid_of_str(NS, -1), vol_rid_of_str;
+  for (uint32_t i = 0; i < n; ++i) {
     const kg_pod& q = d->pods[i];
-    sg.clear();
-    sg.u32(q.ns);
-    sg.range_labels(p, q.labels);
-    sg.range_labels(p, q.node_selector);
-    sg.u32(q.required_terms.count);
-    for (auto& r : kgdesc::ranges(p, q.required_terms)) sg.range_reqs(p, r);
-    sg.u32(q.preferred_terms.count);
-    for (auto& w : kgdesc::span(d->weighted_terms, d->n_weighted_terms, q.preferred_terms, "weighted range")) { sg.u32((uint32_t)w.weight); sg.range_reqs(p, w.reqs); }
-    sg.u32(q.tolerations.count);
-    for (auto& t : kgdesc::tolerations(p, q.tolerations)) { sg.u32(t.key); sg.u32(t.value); sg.u32(t.op); sg.u32(t.effect); }
-    sg.u32(q.spreads.count);
-    for (auto& s : kgdesc::span(d->spreads, d->n_spreads, q.spreads, "spread range")) {
-      sg.u32(s.topology_key); sg.u32((uint32_t)s.max_skew); sg.u32((uint32_t)s.min_domains); sg.u32(s.when_unsatisfiable); sg.selector(p, s.selector);
-    }
-    for (kg_range r : {q.affinity_required, q.affinity_preferred, q.anti_affinity_required, q.anti_affinity_preferred}) {
-      sg.u32(r.count);
-      for (auto& t : kgdesc::span(d->affinity_terms, d->n_affinity_terms, r, "affinity range")) {
-        sg.u32(t.topology_key); sg.selector(p, t.selector); sg.u32((uint32_t)t.weight); sg.u32(t.namespaces.count);
-        for (uint32_t v : kgdesc::values(p, t.namespaces)) sg.u32(v);
-      }
-    }
-    sg.u32(q.host_ports.count);
-    for (auto& h : kgdesc::span(d->host_ports, d->n_host_ports, q.host_ports, "host port range")) { sg.u32(h.ip); sg.u32((uint32_t)h.port); sg.u32(h.protocol); }
-    uint32_t cls = UINT32_MAX;
-    uint32_t slot = (uint32_t)(sg.h >> 20) & tab_mask;
-    for (; tab[slot] != UINT32_MAX; slot = (slot + 1) & tab_mask) {
-      const uint32_t k = tab[slot];
-      if (class_hash[k] == sg.h && sg.same(class_sig[k])) { cls = k; break; }
-    }
-    if (cls == UINT32_MAX) {
-      PodClass c;
-      c.ns = ctx->lab.id(kgdesc::str(p.strings, q.ns));
-      for (auto& l : kgdesc::labels(p, q.labels)) c.labels.push_back({ctx->lab.id(kgdesc::str(p.strings, l.key)), ctx->lab.id(kgdesc::str(p.strings, l.value))});
-      std::sort(c.labels.begin(), c.labels.end());
-      for (auto& l : kgdesc::labels(p, q.node_selector)) {
-        uint32_t k = ctx->V.key(kgdesc::str(p.strings, l.key));
-        c.node_selector.push_back(hreq_new(ctx->V, k, KG_OP_IN, {ctx->V.val(k, kgdesc::str(p.strings, l.value))}, -1));
-      }
-      for (auto& r : kgdesc::ranges(p, q.required_terms)) c.required.push_back(parse_req_list(ctx, p, r));
-      for (auto& w : kgdesc::span(d->weighted_terms, d->n_weighted_terms, q.preferred_terms, "weighted range"))
-        c.preferred.push_back({w.weight, parse_req_list(ctx, p, w.reqs)});
-      for (auto& t : kgdesc::tolerations(p, q.tolerations))
-        c.tols.push_back({t.key == KG_NONE ? -1 : (int)ctx->lab.id(kgdesc::str(p.strings, t.key)),
-                          t.value == KG_NONE ? ctx->lab.id("") : ctx->lab.id(kgdesc::str(p.strings, t.value)), t.op, t.effect});
-      for (auto& s : kgdesc::span(d->spreads, d->n_spreads, q.spreads, "spread range"))
-        c.spreads.push_back({ctx->V.key(kgdesc::str(p.strings, s.topology_key)), s.max_skew, s.min_domains, s.when_unsatisfiable, parse_selector(ctx, p, s.selector)});
-      c.aff_req = parse_terms(ctx, d, q.affinity_required);
-      c.aff_pref = parse_terms(ctx, d, q.affinity_preferred);
-      c.anti_req = parse_terms(ctx, d, q.anti_affinity_required);
-      c.anti_pref = parse_terms(ctx, d, q.anti_affinity_preferred);
-      c.host_ports = q.host_ports.count != 0;
-      for (auto& h : kgdesc::span(d->host_ports, d->n_host_ports, q.host_ports, "host port range"))
-        c.ports.push_back({h.ip == KG_NONE ? -1 : (int)ctx->lab.id(kgdesc::str(p.strings, h.ip)), h.port, (int)h.protocol});
-      cls = (uint32_t)out->classes.size();
-      out->classes.push_back(std::move(c));
-      class_sig.push_back(sg.words());
-      class_hash.push_back(sg.h);
-      tab[slot] = cls;
-      if (class_sig.size() * 2 > tab.size()) {  // keep the table at most half full
-        tab_mask = tab_mask * 2 + 1;
-        tab.assign(tab_mask + 1, UINT32_MAX);
-        for (uint32_t k = 0; k < class_sig.size(); ++k) {
-          uint32_t s2 = (uint32_t)(class_hash[k] >> 20) & tab_mask;
-          while (tab[s2] != UINT32_MAX) s2 = (s2 + 1) & tab_mask;
-          tab[s2] = k;
-        }
-      }
-    }
-    PodRef pr;
-    pr.cls = cls;
-    // the pod's requests, merged by resource and sorted by resource id (resource names resolved once per descriptor string)
-    rl.clear();
     for (auto& qq : kgdesc::quantities(p, q.requests)) {
-      check(qq.name < p.strings.count, "quantity name");
+      check(qq.name < NS, "quantity name");
       int32_t& rid = rid_of_str[qq.name];
       if (rid < 0) rid = (int32_t)ctx->V.resources.id(kgdesc::str(p.strings, qq.name));
-      bool found = false;
-      for (auto& kv : rl) if (kv.first == (uint32_t)rid) { kv.second += qq.milli; found = true; }
-      if (!found) rl.push_back({(uint32_t)rid, qq.milli});
     }
-    if (add_pods_one) {  // resources.RequestsForPods adds pods: 1
-      bool found = false;
-      for (auto& kv : rl) if (kv.first == ctx->rPods) { kv.second += 1000; found = true; }
-      if (!found) rl.push_back({ctx->rPods, 1000});
-    }
-    std::sort(rl.begin(), rl.end());
     if (q.volumes.count) {  // volumes per CSI driver -> requests of the driver's internal resource
+      if (vol_rid_of_str.empty()) vol_rid_of_str.assign(NS, -1);
       for (auto& l : kgdesc::labels(p, q.volumes)) {
+        check(l.key < NS, "volume driver name");
         const std::string drv(kgdesc::str(p.strings, l.key));
-        const uint32_t rid = ctx->V.resources.id(kVolumeResourcePrefix() + drv);
+        int32_t& rid = vol_rid_of_str[l.key];
+        if (rid < 0) rid = (int32_t)ctx->V.resources.id(kVolumeResourcePrefix() + drv);
+        out->vols.push_back(ctx->lab.id(drv + "\x1f" + std::string(kgdesc::str(p.strings, l.value))));
+      }
+    }
+  }
+  struct Chunk {
+    uint32_t lo = 0, hi = 0;
+    ClassTable classes;
+    std::vector<uint32_t> first_pod, global;  // per chunk-local class: the pod that introduced it; its class in `out`
+    std::vector<std::pair<uint32_t, int64_t>> rq;
+    std::string uid;
+    size_t rq_base = 0, uid_base = 0;
+  };
+  KG_PROF("parse_pods: chunks");
+  const unsigned T = host_chunks(n);
+  std::vector<Chunk> chunks(T);
+  for (unsigned t = 0; t < T; ++t) { chunks[t].lo = (uint32_t)((uint64_t)n * t / T); chunks[t].hi = (uint32_t)((uint64_t)n * (t + 1) / T); }
+  const size_t pod_base = out->pods.size();
+  const uint32_t rPods = ctx->rPods;
+  out->pods.resize(pod_base + n);
+  parallel_chunks(T, [&](unsigned t) {
+    Chunk& ch = chunks[t];
+    ch.rq.reserve((size_t)(ch.hi - ch.lo) * 4);
+    ch.uid.reserve((size_t)(ch.hi - ch.lo) * 24);
+    std::vector<std::pair<uint32_t, int64_t>> rl;
+    Sig sg;
+    for (uint32_t i = ch.lo; i < ch.hi; ++i) {
+      const kg_pod& q = d->pods[i];
+      pod_signature(d, q, sg);
+      uint32_t slot = 0;
+      uint32_t cls = ch.classes.find(sg.h, [&](const std::vector<uint32_t>& o) { return sg.same(o); }, &slot);
+      if (cls == UINT32_MAX) {
+        cls = ch.classes.add(sg.h, sg.words(), slot);
+        ch.first_pod.push_back(i);
+      }
+      PodRef& pr = out->pods[pod_base + i];
+      pr.cls = cls;  // (chunk-local until step 3)
+      // the pod's requests, merged by resource and sorted by resource id
+      rl.clear();
+      for (auto& qq : kgdesc::quantities(p, q.requests)) {
+        const uint32_t rid = (uint32_t)rid_of_str[qq.name];
+        bool found = false;
+        for (auto& kv : rl) if (kv.first == rid) { kv.second += qq.milli; found = true; }
+        if (!found) rl.push_back({rid, qq.milli});
+      }
+      if (add_pods_one) {  // resources.RequestsForPods adds pods: 1
+        bool found = false;
+        for (auto& kv : rl) if (kv.first == rPods) { kv.second += 1000; found = true; }
+        if (!found) rl.push_back({rPods, 1000});
+      }
+      for (auto& l : kgdesc::labels(p, q.volumes)) {
+        const uint32_t rid = (uint32_t)vol_rid_of_str[l.key];
         bool found = false;
         for (auto& kv : rl) if (kv.first == rid) { kv.second += 1000; found = true; }
         if (!found) rl.push_back({rid, 1000});
-        out->vols.push_back(ctx->lab.id(drv + "\x1f" + std::string(kgdesc::str(p.strings, l.value))));
       }
       std::sort(rl.begin(), rl.end());
-    }
-    pr.rq_off = (uint32_t)out->rq.size(); pr.rq_n = (uint32_t)rl.size();
-    out->rq.insert(out->rq.end(), rl.begin(), rl.end());
-    {
+      pr.rq_off = (uint32_t)ch.rq.size(); pr.rq_n = (uint32_t)rl.size();
+      ch.rq.insert(ch.rq.end(), rl.begin(), rl.end());
       const std::string_view u = kgdesc::str(p.strings, q.uid);
-      pr.uid_off = (uint32_t)out->uid_pool.size(); pr.uid_len = (uint32_t)u.size();
-      out->uid_pool.append(u.data(), u.size());
+      pr.uid_off = (uint32_t)ch.uid.size(); pr.uid_len = (uint32_t)u.size();
+      ch.uid.append(u.data(), u.size());
+      pr.creation = q.creation_ts;
+      pr.node = q.node;
+      pr.reschedulable = q.reschedulable != 0;
+      pr.priority = q.priority;
+      pr.deletion_cost = q.deletion_cost;
     }
-    pr.creation = q.creation_ts;
-    pr.node = q.node;
-    pr.reschedulable = q.reschedulable != 0;
-    pr.priority = q.priority;
-    pr.deletion_cost = q.deletion_cost;
-    out->pods.push_back(std::move(pr));
+  });
+  KG_PROF("parse_pods: classes");
+  ClassTable all;
+  const uint32_t class_base = (uint32_t)out->classes.size();
+  size_t rq_total = out->rq.size(), uid_total = out->uid_pool.size();
+  for (Chunk& ch : chunks) {
+    ch.global.resize(ch.first_pod.size());
+    for (uint32_t k = 0; k < ch.first_pod.size(); ++k) {
+      std::vector<uint32_t>& words = ch.classes.sig[k];
+      uint32_t slot = 0;
+      uint32_t g = all.find(ch.classes.hash[k], [&](const std::vector<uint32_t>& o) { return o == words; }, &slot);
+      if (g == UINT32_MAX) {
+        out->classes.push_back(pod_class(ctx, d, d->pods[ch.first_pod[k]]));
+        g = all.add(ch.classes.hash[k], std::move(words), slot);
+      }
+      ch.global[k] = class_base + g;
+    }
+    ch.rq_base = rq_total; rq_total += ch.rq.size();
+    ch.uid_base = uid_total; uid_total += ch.uid.size();
   }
+  check(rq_total < UINT32_MAX && uid_total < UINT32_MAX, "pod request / UID pools exceed 4 GiB");
+  KG_PROF("parse_pods: pools");
+  out->rq.resize(rq_total);
+  out->uid_pool.resize(uid_total);
+  parallel_chunks(T, [&](unsigned t) {
+    Chunk& ch = chunks[t];
+    for (uint32_t i = ch.lo; i < ch.hi; ++i) {
+      PodRef& pr = out->pods[pod_base + i];
+      pr.cls = ch.global[pr.cls];
+      pr.rq_off += (uint32_t)ch.rq_base;
+      pr.uid_off += (uint32_t)ch.uid_base;
+    }
+    std::copy(ch.rq.begin(), ch.rq.end(), out->rq.begin() + ch.rq_base);
+    memcpy(&out->uid_pool[0] + ch.uid_base, ch.uid.data(), ch.uid.size());
+  });
   std::sort(out->vols.begin(), out->vols.end());
   out->vols_shared = std::adjacent_find(out->vols.begin(), out->vols.end()) != out->vols.end();
+  KG_PROF("parse_pods: end");
 }
 
 // Volume counts are modelled as additive requests; that is exact as long as every volume belongs to one pod of the call.
@@ -515,21 +622,6 @@ struct SolveInputs {
   uint32_t n_shared = 0;                                  // simulations: pods [0, n_shared) take part in every simulation
 };
 
-// Builds every device table for one Solve over `in.pending`.
-// KG_HOST_PROF=1: wall time of every section of compile_problem to stderr (host-side tuning aid)
-struct HostProf {
-  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-  const char* name = "start";
-  bool on = getenv("KG_HOST_PROF") != nullptr;
-  void mark(const char* next) {
-    if (!on) return;
-    auto n = std::chrono::steady_clock::now();
-    fprintf(stderr, "[kg host] %-42s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(n - t).count());
-    t = n; name = next;
-  }
-};
-#define KG_PROF(x) prof_.mark(x)
-
 // The Queue's order (byCPUAndMemoryDescending, then creation time, then UID) over `keys`: an LSD radix sort on the three
 // numeric fields -- 16-bit digits, the digits no key differs in skipped (cpu and memory requests are a few round values,
 // creation times of a snapshot lie within days: five or six passes in practice) -- then the runs of full ties ordered by UID.
@@ -581,6 +673,22 @@ static void queue_sort(std::vector<QKey>& keys, UidOf uid_of) {
     i = j;
   }
 }
+// Place of every bound pod of a snapshot in the Queue order among the bound pods (a property of the snapshot: simulations sort
+// their few pending pods only and merge).  Reads `bound` and nothing else: kg_cluster_upload runs it beside the caller's thread.
+static void bound_queue_rank(const ParsedPods& bound, uint32_t rCPU, uint32_t rMemory, std::vector<uint32_t>* rank) {
+  const size_t nb = bound.pods.size();
+  std::vector<QKey> bk(nb);
+  for (size_t i = 0; i < nb; ++i) {
+    int64_t c = 0, m = 0;
+    const PodRef& pr = bound.pods[i];
+    for (uint32_t k = pr.rq_off; k < pr.rq_off + pr.rq_n; ++k) { if (bound.rq[k].first == rCPU) c = bound.rq[k].second; if (bound.rq[k].first == rMemory) m = bound.rq[k].second; }
+    bk[i] = QKey{c, m, pr.creation, (uint32_t)i};
+  }
+  queue_sort(bk, [&](uint32_t i) { return bound.uid(bound.pods[i]); });
+  rank->assign(nb, 0);
+  for (size_t r = 0; r < nb; ++r) (*rank)[bk[r].idx] = (uint32_t)r;
+}
+// Builds every device table for one Solve over `in.pending`.
 static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool stats) {
   HostProf prof_;
   kg_ctx* ctx = in.ctx;
@@ -1071,18 +1179,8 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
       // a universe of bound pods: their mutual order is a property of the cluster snapshot (ranked once per kg_cluster),
       // so only the pending pods are sorted here and merged into the bound pods taken in rank order
       const size_t nb = cl->bound.pods.size();
-      if (cl->bound_rank.size() != nb) {
-        std::vector<QKey> bk(nb);
-        for (size_t i = 0; i < nb; ++i) {
-          int64_t c = 0, m = 0;
-          const PodRef& pr = cl->bound.pods[i];
-          for (uint32_t k = pr.rq_off; k < pr.rq_off + pr.rq_n; ++k) { if (cl->bound.rq[k].first == ctx->rCPU) c = cl->bound.rq[k].second; if (cl->bound.rq[k].first == ctx->rMemory) m = cl->bound.rq[k].second; }
-          bk[i] = QKey{c, m, pr.creation, (uint32_t)i};
-        }
-        queue_sort(bk, [&](uint32_t i) { return cl->bound.uid(cl->bound.pods[i]); });
-        cl->bound_rank.assign(nb, 0);
-        for (size_t r = 0; r < nb; ++r) cl->bound_rank[bk[r].idx] = (uint32_t)r;
-      }
+      in.cluster->wait_rank();  // (kg_cluster_upload started it on a thread of its own for large snapshots)
+      if (cl->bound_rank.size() != nb) bound_queue_rank(cl->bound, ctx->rCPU, ctx->rMemory, &in.cluster->bound_rank);
       KG_PROF("pods: merge pending into ranked bound");
       std::vector<uint32_t> at_rank(nb, UINT32_MAX);
       std::vector<QKey> pend_keys, bound_keys;
@@ -1943,6 +2041,15 @@ int32_t kg_cluster_upload(kg_ctx* ctx, const kg_cluster_desc* desc, kg_cluster**
     }
   }
   KG_PROF("upload: end");
+  // the bound pods' Queue ranks (first needed by the first consolidation plan over this snapshot, milliseconds at 10^4+ pods)
+  // are worked out on a thread of their own from here on: it reads cl->bound only, which nothing changes after this point
+  if (cl->bound.pods.size() >= 2 * (size_t)kg::host_chunk_min() && kg::host_threads() > 1) {
+    kg_cluster* c = cl.get();
+    const uint32_t rc = ctx->rCPU, rm = ctx->rMemory;
+    try {
+      c->rank_job = std::async(std::launch::async, [c, rc, rm] { kg::bound_queue_rank(c->bound, rc, rm, &c->bound_rank); });
+    } catch (const std::system_error&) {}  // no thread to be had: ranked at first use instead
+  }
   *out = cl.release();
   return KG_OK;
   KG_GUARD_END(ctx)
@@ -1952,6 +2059,7 @@ int32_t kg_cluster_free(kg_cluster* cl) {
   if (cl) {
     CtxLock lk(cl->ctx);  // (the plans' device buffers are freed on the context's GPU)
     kg_cluster_drop_plans(cl);
+    try { cl->wait_rank(); } catch (...) {}
   }
   delete cl;
   return KG_OK;

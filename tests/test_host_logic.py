@@ -195,3 +195,19 @@ def test_stale_catalog_generation(L):
 def test_volume_limits(L):
     from tests.volume_common import check_volume_limits
     check_volume_limits(L)
+
+
+def test_threaded_descriptor_parsing():
+    """Pod descriptors of 4 096 pods and more are parsed on several host threads (host_threads.hpp) and a large snapshot's
+    Queue ranks on a thread of their own: the same tests in a child process whose environment makes a handful of pods
+    'large' (KG_HOST_CHUNK_MIN=2, four threads) must still agree with the oracle bit for bit."""
+    import subprocess
+    import sys
+    env = dict(os.environ, KG_HOST_CHUNK_MIN="2", KG_HOST_THREADS="4")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
+                        "tests/test_host_logic.py::test_feature_scenarios", "tests/test_host_logic.py::test_volume_limits",
+                        "tests/test_host_logic.py::test_every_refusal_is_reported_and_leaves_the_context_usable",
+                        "tests/test_consolidation_host.py::test_consolidation", "tests/test_consolidation_host.py::test_rounds_reuse_the_prepared_snapshot"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
