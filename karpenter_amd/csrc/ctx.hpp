@@ -37,8 +37,21 @@ struct kg_ctx {
   }
   void pool_give(void* p, size_t bytes) {
     if (!p) return;
-    if (pool.size() >= 6) { kg::hal::dfree(pool.front().ptr); pool.erase(pool.begin()); }
+    if (pool.size() >= 12) { kg::hal::dfree(pool.front().ptr); pool.erase(pool.begin()); }  // (a Solve holds three, a consolidation plan six)
     pool.push_back(kg::DeviceBuffer{p, bytes});
+  }
+  // ... and one page-locked host buffer (a consolidation plan's outcome records)
+  void* pinned_spare = nullptr;
+  size_t pinned_spare_bytes = 0;
+  void* pinned_take(size_t bytes, size_t* got) {
+    if (pinned_spare && pinned_spare_bytes >= bytes) { void* p = pinned_spare; *got = pinned_spare_bytes; pinned_spare = nullptr; pinned_spare_bytes = 0; return p; }
+    *got = bytes;
+    return kg::hal::host_pinned(bytes);
+  }
+  void pinned_give(void* p, size_t bytes) {
+    if (!p) return;
+    if (bytes > pinned_spare_bytes) { std::swap(p, pinned_spare); std::swap(bytes, pinned_spare_bytes); }
+    kg::hal::host_pinned_free(p);
   }
   // Page-locked staging for a call's uploads (problem image, state image, descriptors): copied here and sent without waiting,
   // ordered on the context's stream before the kernels that read them.  One call at a time uses it (under `mu`); a call starts
@@ -66,6 +79,7 @@ struct kg_ctx {
   ~kg_ctx() {
     for (auto& b : pool) kg::hal::dfree(b.ptr);
     kg::hal::host_pinned_free(stage);
+    kg::hal::host_pinned_free(pinned_spare);
     for (auto* m : merged) { kg::hal::dfree(m->tab.dev.ptr); delete m; }
   }
   uint32_t kHostname, kZone, kCT, kZid, kNodePool, kInstanceType;

@@ -2580,7 +2580,19 @@ struct kg_cons_plan {
   size_t max_batch = 0, o_sims = 0, o_unit = 0, o_nq = 0, o_res = 0;
   uint64_t last_use = 0;
   SimResult* results_host = nullptr;  // pinned: the simulations' outcomes come back in one DMA
-  ~kg_cons_plan() { hal::dfree(tables.ptr); hal::dfree(arena.ptr); hal::dfree(run.ptr); hal::host_pinned_free(results_host); }
+  // device buffers and the pinned one come from the context's pools and go back there (a controller that uploads a snapshot per
+  // poll builds a plan per poll: hipMalloc / hipFree / hipHostMalloc of these cost more than the round's kernels)
+  kg_ctx* ctx = nullptr;
+  size_t tables_cap = 0, arena_cap = 0, run_cap = 0, results_cap = 0;
+  void drop_shard() {
+    ctx->pool_give(arena.ptr, arena_cap); ctx->pool_give(run.ptr, run_cap); ctx->pinned_give(results_host, results_cap);
+    arena = DeviceBuffer(); run = DeviceBuffer(); results_host = nullptr;
+  }
+  ~kg_cons_plan() {
+    if (!ctx) return;
+    ctx->pool_give(tables.ptr, tables_cap);
+    drop_shard();
+  }
 };
 void kg_cluster_drop_plans(kg_cluster* cl) { for (auto* p : cl->plans) delete p; cl->plans.clear(); }
 
@@ -2590,6 +2602,7 @@ static std::unique_ptr<kg_cons_plan> build_cons_plan(kg_ctx* ctx, kg_catalog* ca
   Vocab& V = ctx->V;
   auto Pp = std::make_unique<kg_cons_plan>();
   kg_cons_plan& PL = *Pp;
+  PL.ctx = ctx;
   PL.multi = multi || validate;  // (a validated command is a prefix: every candidate of it is taken out of the cluster)
   const uint32_t n = cands->n_candidates;
   PL.n = n;
@@ -2748,7 +2761,7 @@ static std::unique_ptr<kg_cons_plan> build_cons_plan(kg_ctx* ctx, kg_catalog* ca
     PL.o_qoff = PA.add(q_off); PL.o_qent = PA.add(q_ent, 4); PL.o_xoff = PA.add(x_off); PL.o_xnode = PA.add(x_node); PL.o_rem = PA.add(rem_adj);
     PL.o_np = PA.add(nonpending); PL.o_un = PA.add(node_uninit); PL.o_toff = PA.add(t_off); PL.o_tent = PA.add(t_ent); PL.o_guniv = PA.add(C->gdom_univ);
     PL.tables.bytes = PA.bytes.size();
-    PL.tables.ptr = hal::dmalloc(PL.tables.bytes);
+    PL.tables.ptr = ctx->pool_take(PL.tables.bytes, &PL.tables_cap);
     hal::h2d(PL.tables.ptr, PA.bytes.data(), PL.tables.bytes);
   }
 
@@ -2878,13 +2891,12 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
     for (uint32_t k : mine) if (!units[k].skip) PL.live.push_back(k);
     // longest simulations first (the hardware hands workgroups out in launch order: the long ones must not start last)
     std::stable_sort(PL.live.begin(), PL.live.end(), [&](uint32_t a, uint32_t b) { return units[a].pod_hi - units[a].pod_lo > units[b].pod_hi - units[b].pod_lo; });
-    hal::dfree(PL.arena.ptr); hal::dfree(PL.run.ptr); hal::host_pinned_free(PL.results_host);
-    PL.arena = DeviceBuffer(); PL.run = DeviceBuffer(); PL.results_host = nullptr;
+    PL.drop_shard();
     if (!PL.live.empty()) {
       const size_t stride = C->state_bytes, budget = (size_t)8 << 30, nl = PL.live.size();
       PL.max_batch = std::max<size_t>(1, std::min<size_t>(nl, budget / stride > 1 ? budget / stride - 1 : 1));
       PL.arena.bytes = (PL.max_batch + 1) * stride;
-      PL.arena.ptr = hal::dmalloc(PL.arena.bytes);
+      PL.arena.ptr = ctx->pool_take(PL.arena.bytes, &PL.arena_cap);
       // KG_POISON=1 (tests): whatever a simulation reads of its slot beyond the initialised prefix must have been written by it
       if (getenv("KG_POISON")) hal::dfill(PL.arena.ptr, 0xAB, PL.arena.bytes);
       hal::h2d(PL.arena.ptr, C->state_image.data(), C->state_init_bytes);
@@ -2897,9 +2909,9 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
       Arena RA;
       PL.o_sims = RA.add(sims); PL.o_unit = RA.add(PL.live); PL.o_nq = RA.reserve(nl * 4); PL.o_res = RA.reserve(nl * sizeof(SimResult));
       PL.run.bytes = RA.bytes.size();
-      PL.run.ptr = hal::dmalloc(PL.run.bytes);
+      PL.run.ptr = ctx->pool_take(PL.run.bytes, &PL.run_cap);
       hal::h2d(PL.run.ptr, RA.bytes.data(), PL.run.bytes);
-      PL.results_host = (SimResult*)hal::host_pinned(nl * sizeof(SimResult));
+      PL.results_host = (SimResult*)ctx->pinned_take(nl * sizeof(SimResult), &PL.results_cap);
     }
   }
   const std::vector<uint32_t>& live = PL.live;
