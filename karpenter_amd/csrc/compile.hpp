@@ -56,7 +56,11 @@ struct ParsedPods {
   std::vector<PodRef> pods;
   std::vector<std::pair<uint32_t, int64_t>> rq;  // (resource id, milli) pairs of every pod's requests
   std::string uid_pool;                            // the pods' UIDs back to back (Queue order tie-break)
-  std::string_view uid(const PodRef& p) const { return std::string_view(uid_pool).substr(p.uid_off, p.uid_len); }
+  // a set that borrows the two pools of another one instead of holding copies (the pod universe of a consolidation plan over a
+  // snapshot without pending pods: its pods are the snapshot's, offsets unchanged); readers go through rqs() / uid()
+  const ParsedPods* pools_of = nullptr;
+  const std::vector<std::pair<uint32_t, int64_t>>& rqs() const { return pools_of ? pools_of->rq : rq; }
+  std::string_view uid(const PodRef& p) const { return std::string_view(pools_of ? pools_of->uid_pool : uid_pool).substr(p.uid_off, p.uid_len); }
   // volumes (ExistingNode.Add's volume limits): the pods' volume ids, sorted; a pod's count per CSI driver rides in `rq` as a
   // request of the internal resource "karpgpu.internal/volumes/<driver>" (additive as long as no volume is shared)
   std::vector<uint32_t> vols;

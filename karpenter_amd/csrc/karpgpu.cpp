@@ -1072,7 +1072,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   std::vector<int> ract(RG, -1);
   {
     std::vector<uint8_t> used(RG, 0);
-    for (auto& kv : in.pending->rq) if (kv.second != 0) used[kv.first] = 1;  // (every pair in the pool belongs to a pod of this solve)
+    for (auto& kv : in.pending->rqs()) if (kv.second != 0) used[kv.first] = 1;  // (every pair in the pool belongs to a pod of this solve)
     for (auto& tp : C.templates) {
       for (auto& kv : tp.daemon) if (kv.second != 0) used[kv.first] = 1;
       if (tp.has_limits) for (auto& kv : tp.limits) used[kv.first] = 1;
@@ -1156,7 +1156,7 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
   std::vector<int64_t> preq((size_t)std::max(R, 1) * std::max(P, 1), 0);
   std::vector<uint32_t> pod_variant0(std::max(P, 1), 0), queue0(std::max(P, 1), 0);
   for (int p = 0; p < P; ++p) {
-    for (uint32_t k = PP.pods[p].rq_off; k < PP.pods[p].rq_off + PP.pods[p].rq_n; ++k) { const auto& kv = PP.rq[k]; if (ract[kv.first] >= 0) preq[(size_t)p * R + ract[kv.first]] = kv.second; }
+    for (uint32_t k = PP.pods[p].rq_off; k < PP.pods[p].rq_off + PP.pods[p].rq_n; ++k) { const auto& kv = PP.rqs()[k]; if (ract[kv.first] >= 0) preq[(size_t)p * R + ract[kv.first]] = kv.second; }
     pod_variant0[p] = class_variant0[PP.pods[p].cls];
     queue0[p] = (uint32_t)p;
   }
@@ -2620,12 +2620,15 @@ static std::unique_ptr<kg_cons_plan> build_cons_plan(kg_ctx* ctx, kg_catalog* ca
   // the bound pods keep their request pairs and UIDs where the cluster snapshot holds them: both pools are appended whole
   // behind the pending pods' and a bound pod's offsets move by the pending pools' sizes (no copy per pod)
   const uint32_t rq_shift = (uint32_t)pend.rq.size(), uid_shift = (uint32_t)pend.uid_pool.size();
-  U.rq.reserve(pend.rq.size() + cluster->bound.rq.size());
-  U.rq = pend.rq;
-  U.rq.insert(U.rq.end(), cluster->bound.rq.begin(), cluster->bound.rq.end());
-  U.uid_pool.reserve(pend.uid_pool.size() + cluster->bound.uid_pool.size());
-  U.uid_pool = pend.uid_pool;
-  U.uid_pool += cluster->bound.uid_pool;
+  if (pend.pods.empty()) U.pools_of = &cluster->bound;  // (nothing in front of them: borrowed, not copied)
+  else {
+    U.rq.reserve(pend.rq.size() + cluster->bound.rq.size());
+    U.rq = pend.rq;
+    U.rq.insert(U.rq.end(), cluster->bound.rq.begin(), cluster->bound.rq.end());
+    U.uid_pool.reserve(pend.uid_pool.size() + cluster->bound.uid_pool.size());
+    U.uid_pool = pend.uid_pool;
+    U.uid_pool += cluster->bound.uid_pool;
+  }
   const size_t n_bound = cluster->bound.pods.size();
   U.pods.reserve(pend.pods.size() + n_bound);
   nonpending.reserve(pend.pods.size() + n_bound);
@@ -2717,42 +2720,66 @@ static std::unique_ptr<kg_cons_plan> build_cons_plan(kg_ctx* ctx, kg_catalog* ca
   std::vector<uint32_t> shared_sorted;
   for (uint32_t p = 0; p < n_shared; ++p) shared_sorted.push_back(p);
   std::sort(shared_sorted.begin(), shared_sorted.end(), [&](uint32_t a, uint32_t b) { return rank[a] < rank[b]; });
-  std::vector<uint32_t> own, pods;
-  for (size_t k = 0; k < nu; ++k) {
-    const ConsUnit& un = PL.units[k];
-    q_off[k] = (uint32_t)(q_ent.size() / 4);
-    x_off[k] = (uint32_t)x_node.size();
-    t_off[k] = (uint32_t)t_ent.size();
-    if (un.skip) continue;
-    own.clear();
-    for (uint32_t p = un.pod_lo; p < un.pod_hi; ++p) own.push_back(p);
-    std::sort(own.begin(), own.end(), [&](uint32_t a, uint32_t b) { return rank[a] < rank[b]; });
-    pods.resize(shared_sorted.size() + own.size());
-    std::merge(shared_sorted.begin(), shared_sorted.end(), own.begin(), own.end(), pods.begin(), [&](uint32_t a, uint32_t b) { return rank[a] < rank[b]; });
-    for (uint32_t p : pods) { q_ent.push_back(p); q_ent.push_back(C->pod_variant0[p]); q_ent.push_back(0); q_ent.push_back(0); }
-    if (!C->contrib.empty())
-      for (uint32_t p = un.pod_lo; p < un.pod_hi; ++p) t_ent.insert(t_ent.end(), C->contrib[p].begin(), C->contrib[p].end());
-    const uint32_t c0 = PL.multi ? 0 : un.id, c1 = un.id + 1;
-    for (uint32_t ci = c0; ci < c1; ++ci) {
-      const int nd = cands->candidates[ci];
-      if (pos_of_node[nd] >= 0) x_node.push_back((uint32_t)pos_of_node[nd]);
-      if (any_limits && pos_of_node[nd] >= 0) {
-        // the scheduler of a simulation does not charge the candidates against their NodePool's limits
-        uint32_t npv = UINT32_MAX;
-        for (auto& kv : cluster->nodes[nd].labels) if (kv.first == ctx->kNodePool) npv = kv.second;
-        if (npv == UINT32_MAX) continue;
-        for (int t = 0; t < NP; ++t) {
-          const auto& tp = C->templates[t];
-          if (!(tp.has_limits && !tp.limits.empty()) || V.vals[ctx->kNodePool].strs[npv] != tp.name) continue;
-          for (auto& kv : cluster->nodes[nd].capacity) {
-            bool limited = false;
-            for (auto& lv : tp.limits) limited |= lv.first == kv.first;
-            if (limited && ract[kv.first] >= 0) rem_adj[k * (size_t)R * NP + (size_t)ract[kv.first] * NP + t] += kv.second;
+  // (units in contiguous chunks on the host's threads, each into its own vectors: offsets are chunk-relative until the chunks'
+  // sizes are known, then every chunk copies its part into place)
+  size_t patch_work = 0;
+  for (auto& un : PL.units) if (!un.skip) patch_work += n_shared + un.pod_hi - un.pod_lo;
+  const unsigned TC = (unsigned)std::min<size_t>(host_chunks(patch_work), std::max<size_t>(nu, 1));
+  struct PatchChunk { size_t k0 = 0, k1 = 0, q_base = 0, x_base = 0, t_base = 0; std::vector<uint32_t> q_ent, x_node, t_ent; };
+  std::vector<PatchChunk> pch(TC);
+  for (unsigned t = 0; t < TC; ++t) { pch[t].k0 = nu * t / TC; pch[t].k1 = nu * (t + 1) / TC; }
+  parallel_chunks(TC, [&](unsigned t) {
+    PatchChunk& ch = pch[t];
+    std::vector<uint32_t> own, pods;
+    for (size_t k = ch.k0; k < ch.k1; ++k) {
+      const ConsUnit& un = PL.units[k];
+      q_off[k] = (uint32_t)(ch.q_ent.size() / 4);
+      x_off[k] = (uint32_t)ch.x_node.size();
+      t_off[k] = (uint32_t)ch.t_ent.size();
+      if (un.skip) continue;
+      own.clear();
+      for (uint32_t p = un.pod_lo; p < un.pod_hi; ++p) own.push_back(p);
+      std::sort(own.begin(), own.end(), [&](uint32_t a, uint32_t b) { return rank[a] < rank[b]; });
+      pods.resize(shared_sorted.size() + own.size());
+      std::merge(shared_sorted.begin(), shared_sorted.end(), own.begin(), own.end(), pods.begin(), [&](uint32_t a, uint32_t b) { return rank[a] < rank[b]; });
+      for (uint32_t p : pods) { ch.q_ent.push_back(p); ch.q_ent.push_back(C->pod_variant0[p]); ch.q_ent.push_back(0); ch.q_ent.push_back(0); }
+      if (!C->contrib.empty())
+        for (uint32_t p = un.pod_lo; p < un.pod_hi; ++p) ch.t_ent.insert(ch.t_ent.end(), C->contrib[p].begin(), C->contrib[p].end());
+      const uint32_t c0 = PL.multi ? 0 : un.id, c1 = un.id + 1;
+      for (uint32_t ci = c0; ci < c1; ++ci) {
+        const int nd = cands->candidates[ci];
+        if (pos_of_node[nd] >= 0) ch.x_node.push_back((uint32_t)pos_of_node[nd]);
+        if (any_limits && pos_of_node[nd] >= 0) {
+          // the scheduler of a simulation does not charge the candidates against their NodePool's limits
+          uint32_t npv = UINT32_MAX;
+          for (auto& kv : cluster->nodes[nd].labels) if (kv.first == ctx->kNodePool) npv = kv.second;
+          if (npv == UINT32_MAX) continue;
+          for (int tpi = 0; tpi < NP; ++tpi) {
+            const auto& tp = C->templates[tpi];
+            if (!(tp.has_limits && !tp.limits.empty()) || V.vals[ctx->kNodePool].strs[npv] != tp.name) continue;
+            for (auto& kv : cluster->nodes[nd].capacity) {
+              bool limited = false;
+              for (auto& lv : tp.limits) limited |= lv.first == kv.first;
+              if (limited && ract[kv.first] >= 0) rem_adj[k * (size_t)R * NP + (size_t)ract[kv.first] * NP + tpi] += kv.second;
+            }
           }
         }
       }
     }
+  });
+  {
+    size_t qn = 0, xn = 0, tn = 0;
+    for (auto& ch : pch) { ch.q_base = qn; ch.x_base = xn; ch.t_base = tn; qn += ch.q_ent.size(); xn += ch.x_node.size(); tn += ch.t_ent.size(); }
+    check(qn / 4 < UINT32_MAX && xn < UINT32_MAX && tn < UINT32_MAX, "consolidation patches exceed 2^32 entries");
+    q_ent.resize(qn); x_node.resize(xn); t_ent.resize(tn);
   }
+  parallel_chunks(TC, [&](unsigned t) {
+    PatchChunk& ch = pch[t];
+    for (size_t k = ch.k0; k < ch.k1; ++k) { q_off[k] += (uint32_t)(ch.q_base / 4); x_off[k] += (uint32_t)ch.x_base; t_off[k] += (uint32_t)ch.t_base; }
+    std::copy(ch.q_ent.begin(), ch.q_ent.end(), q_ent.begin() + ch.q_base);
+    std::copy(ch.x_node.begin(), ch.x_node.end(), x_node.begin() + ch.x_base);
+    std::copy(ch.t_ent.begin(), ch.t_ent.end(), t_ent.begin() + ch.t_base);
+  });
   q_off[nu] = (uint32_t)(q_ent.size() / 4);
   x_off[nu] = (uint32_t)x_node.size();
   t_off[nu] = (uint32_t)t_ent.size();
