@@ -3079,7 +3079,28 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
     order_by_price(cat, &all, zmask, ctmask);
     return all;
   };
+  // the zones and capacity types a simulation's one NodeClaim still allows
+  auto claim_masks = [&](const SimResult& sr, uint64_t* zmask, uint64_t* ctmask) {
+    *zmask = allowed1(sr.zone_meta, sr.zone_word);
+    *ctmask = allowed1(sr.ct_meta, sr.ct_word);
+    const uint64_t zidm = allowed1(sr.zid_meta, sr.zid_word);
+    if (sr.zid_meta & RM_PRESENT)
+      for (int z = 0; z < 64; ++z) if (zone_zid[z] != 0xFF && !((zidm >> zone_zid[z]) & 1)) *zmask &= ~(1ull << z);
+  };
+  // the price orders of the round's distinct mask pairs first (a handful), so that the simulations below -- independent of
+  // each other, one record each -- only read them and can be spread over the host's threads
+  size_t n_priced = 0;
   for (size_t li = 0; li < live.size(); ++li) {
+    const SimResult& sr = results[li];
+    if (sr.errors != 0 || sr.nclaims != 1) continue;
+    uint64_t zm, cm;
+    claim_masks(sr, &zm, &cm);
+    price_order(zm, cm);
+    n_priced += 1;
+  }
+  const unsigned TD = (unsigned)std::min<size_t>(host_chunks(n_priced * 8), std::max<size_t>(live.size(), 1));
+  parallel_chunks(TD, [&](unsigned td) {
+  for (size_t li = live.size() * td / TD; li < live.size() * (td + 1) / TD; ++li) {
     const ConsUnit& un = units[live[li]];
     const SimResult& sr = results[li];
     kg_candidate_record& rec = records[rec_of_unit[live[li]]];
@@ -3093,16 +3114,15 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
       // Results.TruncateInstanceTypes comes before any price: the claim's options in price order, cut to the maximum,
       // minValues (the merged requirements of the claim carry its NodePool's) checked on what is left
       rp.nodepool = C->templates[sr.tmpl].index;
-      rp.zmask = allowed1(sr.zone_meta, sr.zone_word);
-      rp.ctmask = allowed1(sr.ct_meta, sr.ct_word);
-      const uint64_t zidm = allowed1(sr.zid_meta, sr.zid_word);
-      if (sr.zid_meta & RM_PRESENT)
-        for (int z = 0; z < 64; ++z) if (zone_zid[z] != 0xFF && !((zidm >> zone_zid[z]) & 1)) rp.zmask &= ~(1ull << z);
+      claim_masks(sr, &rp.zmask, &rp.ctmask);
       // OrderByPrice of the claim's options = the catalog-wide order for these (zone, capacity-type) masks, filtered by the
       // claim's type mask (a stable sort of a subset keeps the relative order of the stable sort of the whole); a round
       // sees a handful of distinct mask pairs, so the sort runs that many times instead of once per simulation.  Only
       // the first max_instance_types of the order are ever looked at.
-      const std::vector<uint32_t>& order = price_order(rp.zmask, rp.ctmask);
+      const std::vector<uint32_t>* order_p = nullptr;
+      for (auto& o : orders) if (o.zmask == rp.zmask && o.ctmask == rp.ctmask) order_p = &o.order;
+      check(order_p != nullptr, "price order of a claim's masks");
+      const std::vector<uint32_t>& order = *order_p;
       const size_t limit = nodepools->max_instance_types > 0 ? (size_t)nodepools->max_instance_types : order.size();
       for (uint32_t t : order) {
         if (t >= (uint32_t)(std::min(C->TW, (int)KG_TWLDS) * 64) || !((sr.mask[t >> 6] >> (t & 63)) & 1)) continue;
@@ -3178,6 +3198,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
       }
     }
   }
+  });
   KG_PROF("cons: end");
   return KG_OK;
   KG_GUARD_END(ctx)
