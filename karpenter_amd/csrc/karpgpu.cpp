@@ -2789,7 +2789,7 @@ static std::unique_ptr<kg_cons_plan> build_cons_plan(kg_ctx* ctx, kg_catalog* ca
     PL.o_np = PA.add(nonpending); PL.o_un = PA.add(node_uninit); PL.o_toff = PA.add(t_off); PL.o_tent = PA.add(t_ent); PL.o_guniv = PA.add(C->gdom_univ);
     PL.tables.bytes = PA.bytes.size();
     PL.tables.ptr = ctx->pool_take(PL.tables.bytes, &PL.tables_cap);
-    hal::h2d(PL.tables.ptr, PA.bytes.data(), PL.tables.bytes);
+    ctx->upload(PL.tables.ptr, PA.bytes.data(), PL.tables.bytes, true);  // (copied to the staging buffer: PA may go)
   }
 
   KG_PROF("plan: candidate prices");
@@ -2852,6 +2852,7 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
   *n_records = 0;
   if (device_ms) *device_ms = 0;
   HostProf prof_;
+  ctx->stage_off = 0;  // (every earlier call ended in a wait: its staged uploads have landed)
   std::optional<hal::Range> phase;
   phase.emplace("kg_consolidate: plan");
   KG_PROF("cons: plan lookup");
@@ -2923,10 +2924,12 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
       const size_t stride = C->state_bytes, budget = (size_t)8 << 30, nl = PL.live.size();
       PL.max_batch = std::max<size_t>(1, std::min<size_t>(nl, budget / stride > 1 ? budget / stride - 1 : 1));
       PL.arena.bytes = (PL.max_batch + 1) * stride;
+      KG_PROF("cons: shard: state slots");
       PL.arena.ptr = ctx->pool_take(PL.arena.bytes, &PL.arena_cap);
       // KG_POISON=1 (tests): whatever a simulation reads of its slot beyond the initialised prefix must have been written by it
       if (getenv("KG_POISON")) hal::dfill(PL.arena.ptr, 0xAB, PL.arena.bytes);
-      hal::h2d(PL.arena.ptr, C->state_image.data(), C->state_init_bytes);
+      ctx->upload(PL.arena.ptr, C->state_image.data(), C->state_init_bytes, true);
+      KG_PROF("cons: shard: state descriptors");
       std::vector<SimState> sims(nl);
       for (size_t i = 0; i < nl; ++i) {
         sims[i] = sim_at(*C, (uint8_t*)PL.arena.ptr + (i % PL.max_batch + 1) * stride);
@@ -2936,8 +2939,10 @@ static int32_t consolidate_impl(kg_ctx* ctx, kg_catalog* const* catalogs, uint32
       Arena RA;
       PL.o_sims = RA.add(sims); PL.o_unit = RA.add(PL.live); PL.o_nq = RA.reserve(nl * 4); PL.o_res = RA.reserve(nl * sizeof(SimResult));
       PL.run.bytes = RA.bytes.size();
+      KG_PROF("cons: shard: upload");
       PL.run.ptr = ctx->pool_take(PL.run.bytes, &PL.run_cap);
-      hal::h2d(PL.run.ptr, RA.bytes.data(), PL.run.bytes);
+      // (staged and not waited for: ordered on the context's stream before the round's kernels, which end in a wait)
+      ctx->upload(PL.run.ptr, RA.bytes.data(), PL.run.bytes, true);
       PL.results_host = (SimResult*)ctx->pinned_take(nl * sizeof(SimResult), &PL.results_cap);
     }
   }
