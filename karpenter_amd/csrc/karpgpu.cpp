@@ -1188,19 +1188,22 @@ static std::unique_ptr<Compiled> compile_problem(const SolveInputs& in, bool sta
         const int32_t bi = (*in.universe_bound)[p];
         if (bi >= 0) at_rank[cl->bound_rank[bi]] = (uint32_t)p; else pend_keys.push_back(qkey((uint32_t)p));
       }
-      bound_keys.reserve((size_t)P);
-      for (size_t r = 0; r < nb; ++r) if (at_rank[r] != UINT32_MAX) bound_keys.push_back(qkey(at_rank[r]));
-      queue_sort(pend_keys, [&](uint32_t i) { return PP.uid(PP.pods[i]); });
-      if (pend_keys.empty()) keys.swap(bound_keys);
-      else {
+      if (pend_keys.empty()) {  // (nothing to merge: the Queue is the bound pods of the universe in rank order, no key needed)
+        size_t k = 0;
+        for (size_t r = 0; r < nb; ++r) if (at_rank[r] != UINT32_MAX) queue0[k++] = at_rank[r];
+      } else {
+        bound_keys.reserve((size_t)P);
+        for (size_t r = 0; r < nb; ++r) if (at_rank[r] != UINT32_MAX) bound_keys.push_back(qkey(at_rank[r]));
+        queue_sort(pend_keys, [&](uint32_t i) { return PP.uid(PP.pods[i]); });
         keys.resize(pend_keys.size() + bound_keys.size());
         std::merge(pend_keys.begin(), pend_keys.end(), bound_keys.begin(), bound_keys.end(), keys.begin(), qless);
+        for (int p = 0; p < P; ++p) queue0[p] = keys[p].idx;
       }
     } else {
       for (int p = 0; p < P; ++p) keys.push_back(qkey((uint32_t)p));
       queue_sort(keys, [&](uint32_t i) { return PP.uid(PP.pods[i]); });
+      for (int p = 0; p < P; ++p) queue0[p] = keys[p].idx;
     }
-    for (int p = 0; p < P; ++p) queue0[p] = keys[p].idx;
   }
 
   KG_PROF("templates -> device rows");
@@ -2800,6 +2803,7 @@ static std::unique_ptr<kg_cons_plan> build_cons_plan(kg_ctx* ctx, kg_catalog* ca
   // (a candidate's instance type is resolved among the types of ITS NodePool: instanceTypeMap[nodePool][name] upstream)
   std::unordered_map<std::string, int> type_by_name;
   for (size_t t = 0; t < cat->types.size(); ++t) type_by_name.emplace(std::to_string(cat->part_begin.empty() ? 0 : cat->part_of((uint32_t)t)) + "/" + cat->types[t].name, (int)t);
+  std::unordered_map<uint64_t, int> type_of_value;
   std::unordered_map<std::string, uint32_t> part_of_pool;
   for (uint32_t i = 0; i < nodepools->n_nodepools; ++i)
     part_of_pool.emplace(std::string(kgdesc::str(nodepools->pools.strings, nodepools->nodepools[i].name)), cat->part_begin.empty() ? 0 : nodepools->nodepools[i].catalog);
@@ -2823,9 +2827,15 @@ static std::unique_ptr<kg_cons_plan> build_cons_plan(kg_ctx* ctx, kg_catalog* ca
       if (pf == part_of_pool.end()) continue;  // (not a node of one of these NodePools: no instance type to price)
       part = pf->second;
     }
-    auto f = type_by_name.find(std::to_string(part) + "/" + V.vals[ctx->kInstanceType].strs[itv]);
-    if (f == type_by_name.end()) continue;
-    ci.type = f->second;
+    // (thousands of candidates, a few dozen instance types among them: the name is looked up once per (catalog, label value))
+    const uint64_t tk = ((uint64_t)part << 32) | (uint32_t)itv;
+    auto known = type_of_value.find(tk);
+    if (known == type_of_value.end()) {
+      auto f = type_by_name.find(std::to_string(part) + "/" + V.vals[ctx->kInstanceType].strs[itv]);
+      known = type_of_value.emplace(tk, f == type_by_name.end() ? -1 : f->second).first;
+    }
+    if (known->second < 0) continue;
+    ci.type = known->second;
     for (auto& o : cat->types[ci.type].offerings) {
       if (zone >= 0 && (int)o.zone != zone) continue;
       if (ctv >= 0 && (int)o.ct != ctv) continue;
