@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""The cold-round figures of bench.py JSON lines, one file per line: python tools/bench_cold_of.py BENCH.json ..."""
 import json,sys
 for f in sys.argv[1:]:
     d=json.loads(open(f).read().strip().splitlines()[-1])
