@@ -3,8 +3,15 @@
 #include <mutex>
 #include <string>
 
+#include <memory>
+
 #include "hal.hpp"
 #include "host_model.hpp"
+
+namespace kg {
+struct ParsedPods;  // compile.hpp
+void parsed_pods_delete(ParsedPods* p);
+}  // namespace kg
 
 struct kg_ctx {
   kg::Vocab V;
@@ -73,6 +80,9 @@ struct kg_ctx {
     kg::hal::h2d_async(dst, (uint8_t*)stage + stage_off, bytes);
     stage_off = (stage_off + bytes + 255) & ~size_t(255);
   }
+  // the pod pools of the last cluster snapshot freed on this context, kept for the next upload: their capacity only -- a controller
+  // that uploads a snapshot per poll otherwise faults the same megabytes in again every time (glibc unmaps them at the free)
+  std::unique_ptr<kg::ParsedPods, void (*)(kg::ParsedPods*)> spare_bound{nullptr, kg::parsed_pods_delete};
   // merged views of the catalog sets recent solves named (at most 2 kept); owned by the context
   std::vector<kg_catalog*> merged;
   uint64_t merged_clock = 0;

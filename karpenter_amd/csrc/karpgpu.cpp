@@ -216,6 +216,8 @@ struct ClassTable {
 // one thread each, nothing shared but the descriptor and step 1's table: signature, chunk-local class, requests, UID.
 // (3) serial over the chunks' classes in order (= order of first appearance over all pods, what one serial pass numbers them
 // by): the vocabulary is touched here only; then the chunks copy their pools into place.  One chunk below 4 096 pods.
+void parsed_pods_delete(ParsedPods* p) { delete p; }
+
 void parse_pods(kg_ctx* ctx, const kg_pods_desc* d, ParsedPods* out, bool add_pods_one) {
   if (!d) return;
   const kg_pools& p = d->pools;
@@ -2025,6 +2027,12 @@ int32_t kg_cluster_upload(kg_ctx* ctx, const kg_cluster_desc* desc, kg_cluster**
     cl->nodes.push_back(std::move(cn));
   }
   KG_PROF("upload: bound pods");
+  if (ctx->spare_bound) {  // (the pools of the last snapshot freed here: emptied, their pages still mapped)
+    ParsedPods& sp = *ctx->spare_bound;
+    cl->bound.pods = std::move(sp.pods); cl->bound.rq = std::move(sp.rq); cl->bound.uid_pool = std::move(sp.uid_pool);
+    cl->bound.pods.clear(); cl->bound.rq.clear(); cl->bound.uid_pool.clear();
+    ctx->spare_bound.reset();
+  }
   parse_pods(ctx, &desc->pods, &cl->bound, true);
   KG_PROF("upload: volume limits");
   for (auto& bp : cl->bound.pods) check(bp.node >= 0 && bp.node < (int)cl->nodes.size(), "bound pod node index");
@@ -2063,6 +2071,14 @@ int32_t kg_cluster_free(kg_cluster* cl) {
     CtxLock lk(cl->ctx);  // (the plans' device buffers are freed on the context's GPU)
     kg_cluster_drop_plans(cl);
     try { cl->wait_rank(); } catch (...) {}
+    kg_ctx* ctx = cl->ctx;
+    if (!ctx->spare_bound || ctx->spare_bound->pods.capacity() < cl->bound.pods.capacity()) {
+      ParsedPods* sp = new (std::nothrow) ParsedPods();
+      if (sp) {
+        sp->pods = std::move(cl->bound.pods); sp->rq = std::move(cl->bound.rq); sp->uid_pool = std::move(cl->bound.uid_pool);
+        ctx->spare_bound.reset(sp);
+      }
+    }
   }
   delete cl;
   return KG_OK;
